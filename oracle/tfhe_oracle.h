@@ -1,0 +1,150 @@
+/*
+ * tfhe_oracle.h -- CPU restatement of go-tfhe's gate-bootstrap path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product path (go-tfhe_amd/) never links, imports or falls back to it.
+ *
+ * PARITY PIN STATUS: "parity unpinned" at the ciphertext-sample level.
+ * The reference (pure Go, no Go toolchain in this image) cannot be built or run
+ * here, and its own tests hold no golden ciphertexts / seeded RNG for this path
+ * (SURVEY.md section 4, 8c).  What the reference's tests DO pin is checked in
+ * tests/test_oracle_*.py: the F64ToTorus known answers (utils/utils_test.go:15-20),
+ * the FFT round trip bound (poly/poly_test.go:10-33), the gate truth tables
+ * (gates/gates_test.go:23-366) and the PBS identity/complement/modulo cases
+ * (params/uint_params_test.go:17-147).  Beyond that the restatement is pinned
+ * against an implementation-independent exact-integer negacyclic product
+ * (orc_negacyclic_exact), which the fp64 FFT pipeline must equal bit-for-bit at
+ * the N=1024 parameter sets (pre-rounding error ~0.004 << 0.5).
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it
+ * restates.  All u32 arithmetic wraps mod 2^32.
+ */
+#ifndef TFHE_ORACLE_H
+#define TFHE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* params/params.go:60-78 (the TRGSWLv1/TLWELv0 fields the path reads). */
+typedef struct {
+    int32_t n;        /* TLWELv0.N  : LWE dimension                      */
+    int32_t N;        /* TRGSWLv1.N : ring degree                        */
+    int32_t Nbit;     /* log2 N                                          */
+    int32_t L;        /* gadget levels                                   */
+    int32_t Bgbit;    /* log2 gadget base                                */
+    int32_t basebit;  /* key-switch base bits                            */
+    int32_t t;        /* IKS_T key-switch levels                         */
+    double  alpha_lv0;/* TLWELv0.ALPHA (KSKAlpha, params.go:629)         */
+    double  alpha_lv1;/* TLWELv1.ALPHA (BSKAlpha, params.go:634)         */
+} orc_params;
+
+/* Named sets: 0 = 80-bit (params.go:83-112), 1 = 110-bit (:117-146),
+ * 2 = 128-bit (:151-180), 3 = Uint5 (:362-391). Returns 0 on success. */
+int orc_get_params(int which, orc_params *out);
+
+/* ---- scalar helpers ---------------------------------------------------- */
+uint32_t orc_f64_to_torus(double d);                      /* utils/utils.go:11-14 */
+uint32_t orc_decomposition_offset(const orc_params *p);   /* cloudkey/cloudkey.go:60-71 */
+
+/* ---- poly layer (poly/) ------------------------------------------------ */
+/* Opaque twiddle tables for one ring degree (poly_evaluator.go:76-143). */
+typedef struct orc_fft orc_fft;
+orc_fft *orc_fft_new(int N);
+void     orc_fft_free(orc_fft *f);
+
+/* ToFourierPolyAssign: fold + forward FFT (fourier_transform.go:18-21,64-85,178-247).
+ * fp has N doubles in the reference FourierPoly layout ([4 re | 4 im] blocks). */
+void orc_to_fourier(const orc_fft *f, const uint32_t *p, double *fp);
+/* ToPolyAssignUnsafe: inverse FFT + mod-Q round + unfold (:40-44,258-347,88-125).
+ * Destroys fp.  If pre_round != NULL the N pre-rounding doubles are copied there. */
+void orc_to_poly(const orc_fft *f, double *fp, uint32_t *p, double *pre_round);
+/* elementWiseMulAddCmplxAssign (fourier_ops.go:167-191): out += v0*v1. */
+void orc_fourier_mul_add(int N, const double *v0, const double *v1, double *out);
+/* DecomposePolyAssign (decomposer.go:55-66): out[L][N]. */
+void orc_decompose(const orc_params *p, const uint32_t *poly, uint32_t offset, uint32_t *out);
+/* PolyMulWithXKInPlace (buffer_methods.go:133-164). */
+void orc_poly_mul_xk(int N, const uint32_t *a, int k, uint32_t *out);
+/* Exact negacyclic product a*b mod (X^N+1, 2^32); a read as int32 (digits), b as u32. */
+void orc_negacyclic_exact(int N, const uint32_t *a, const uint32_t *b, uint32_t *out);
+
+/* ---- ciphertext path (trgsw/, evaluator/, trlwe/) ------------------------ */
+/* ExternalProductAssign (evaluator.go:50-81).  bsk_i: one TRGSW in Fourier form,
+ * [2L][2][N] doubles (row r, part 0=A 1=B).  in/out: [2][N] u32 (A then B). */
+void orc_external_product(const orc_params *p, const orc_fft *f, const double *bsk_i,
+                          const uint32_t *in, uint32_t *out);
+/* Same contraction with exact integer arithmetic; bsk_i_torus: [2L][2][N] u32. */
+void orc_external_product_exact(const orc_params *p, const uint32_t *bsk_i_torus,
+                                const uint32_t *in, uint32_t *out);
+/* CMuxAssign (evaluator.go:85-106): out = ct0 + bsk_i (x) (ct1 - ct0); may alias ct0. */
+void orc_cmux(const orc_params *p, const orc_fft *f, const double *bsk_i,
+              const uint32_t *ct0, const uint32_t *ct1, uint32_t *out);
+/* BlindRotateAssign (evaluator.go:110-135). bsk: [n][2L][2][N] doubles. nsteps<0 => n.
+ * (nsteps lets tests stop after a prefix of the chain.) */
+void orc_blind_rotate(const orc_params *p, const orc_fft *f, const double *bsk,
+                      const uint32_t *ct, const uint32_t *testvec, int nsteps, uint32_t *out);
+/* Exact-integer version of the same chain; bsk_torus: [n][2L][2][N] u32. */
+void orc_blind_rotate_exact(const orc_params *p, const uint32_t *bsk_torus,
+                            const uint32_t *ct, const uint32_t *testvec, int nsteps,
+                            uint32_t *out);
+/* SampleExtractIndexAssign (trlwe_ops.go:10-21); out has N+1 words. */
+void orc_sample_extract(int N, const uint32_t *trlwe, int k, uint32_t *out);
+/* IdentityKeySwitchingAssign (keyswitch.go:10-37); ksk: [N*t*base][n+1]. */
+void orc_key_switch(const orc_params *p, const uint32_t *ksk, const uint32_t *lv1, uint32_t *out);
+/* BootstrapAssign / BootstrapLUTAssign (evaluator.go:139-148, programmable_bootstrap.go:93-115). */
+void orc_bootstrap(const orc_params *p, const orc_fft *f, const double *bsk, const uint32_t *ksk,
+                   const uint32_t *ct, const uint32_t *testvec, uint32_t *out);
+
+/* ---- gates (gates/gates.go, evaluator/gates_helper.go) -------------------- */
+enum {
+    ORC_NAND = 0, ORC_AND = 1, ORC_OR = 2, ORC_XOR = 3, ORC_XNOR = 4, ORC_NOR = 5,
+    ORC_ANDNY = 6, ORC_ANDYN = 7, ORC_ORNY = 8, ORC_ORYN = 9, ORC_MUX = 10
+};
+/* Linear prep of a binary gate (gates_helper.go:10-63, gates.go:52-104). */
+int  orc_gate_prepare(const orc_params *p, int op, const uint32_t *a, const uint32_t *b, uint32_t *out);
+/* genTestvec (cloudkey.go:74-85): [2][N]. */
+void orc_gate_testvec(const orc_params *p, uint32_t *tv);
+/* One gate = prepare + bootstrap; MUX = 3 bootstraps (gates.go:107-114); c may be NULL. */
+int  orc_gate(const orc_params *p, const orc_fft *f, const double *bsk, const uint32_t *ksk,
+              int op, const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *out);
+/* B independent gates, one per OpenMP thread (mirrors trgsw.go:234-252). ops: per item
+ * if op_uniform<0 else all = op_uniform. Returns threads used. */
+int  orc_gate_batch(const orc_params *p, const double *bsk, const uint32_t *ksk,
+                    const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b,
+                    const uint32_t *c, uint32_t *out, int B, int nthreads);
+int  orc_bootstrap_batch(const orc_params *p, const double *bsk, const uint32_t *ksk,
+                         const uint32_t *ct, const uint32_t *testvec, int testvec_per_item,
+                         uint32_t *out, int B, int nthreads);
+
+/* ---- harness: our own seeded keygen / encrypt / decrypt / LUT -------------- */
+typedef struct { uint64_t s[4]; int have_spare; double spare; } orc_rng;
+void     orc_rng_seed(orc_rng *r, uint64_t seed);   /* xoshiro256** via splitmix64 */
+uint64_t orc_rng_u64(orc_rng *r);
+double   orc_rng_normal(orc_rng *r);                /* Box-Muller */
+
+void orc_keygen_secret(const orc_params *p, orc_rng *r, uint32_t *s0 /*n*/, uint32_t *s1 /*N*/); /* key/key.go:16-45 */
+void orc_tlwe_encrypt_f64(const orc_params *p, orc_rng *r, double mu, double alpha,
+                          const uint32_t *s0, uint32_t *ct);                   /* tlwe/tlwe.go:36-50 */
+void orc_tlwe_encrypt_bool(const orc_params *p, orc_rng *r, int bit, const uint32_t *s0, uint32_t *ct); /* :53-61 */
+int  orc_tlwe_decrypt_bool(const orc_params *p, const uint32_t *s0, const uint32_t *ct);               /* :64-73 */
+uint32_t orc_tlwe_phase(const orc_params *p, const uint32_t *s0, const uint32_t *ct);
+void orc_tlwe_encrypt_message(const orc_params *p, orc_rng *r, int msg, int modulus,
+                              const uint32_t *s0, uint32_t *ct);               /* programmable_encrypt.go:12-26 */
+int  orc_tlwe_decrypt_message(const orc_params *p, int modulus, const uint32_t *s0, const uint32_t *ct); /* :32-54 */
+/* genBootstrappingKey (cloudkey.go:123-145, trgsw.go:32-82). Writes the torus-domain key
+ * [n][2L][2][N] u32 (may be NULL) and/or its Fourier form [n][2L][2][N] doubles (may be NULL). */
+void orc_keygen_bsk(const orc_params *p, orc_rng *r, const uint32_t *s0, const uint32_t *s1,
+                    uint32_t *bsk_torus, double *bsk_fourier);
+/* genKeySwitchingKey (cloudkey.go:88-120): [N*t*base][n+1] u32, k=0 rows all zero. */
+void orc_keygen_ksk(const orc_params *p, orc_rng *r, const uint32_t *s0, const uint32_t *s1, uint32_t *ksk);
+/* GenLookUpTableAssign (lut/generator.go:56-100) + Encode (lut/encoder.go:47-74):
+ * table[x] = f(x) for x<modulus; out testvec [2][N] with A=0. */
+void orc_lut_generate(const orc_params *p, const int32_t *table, int modulus, uint32_t *tv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
