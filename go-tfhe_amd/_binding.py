@@ -1,0 +1,275 @@
+"""ctypes binding of include/tfhe_hip.h."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from .build import LIB_PATH
+from .params import Params
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "tfhe_hip.h")
+
+OPS = {"NAND": 0, "AND": 1, "OR": 2, "XOR": 3, "XNOR": 4, "NOR": 5,
+       "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9, "MUX": 10}
+
+_lib = None
+
+
+class TfheError(RuntimeError):
+    """A non-zero return from the C ABI (the reference panics at the same places)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"tfhe_hip error {code}: {msg}")
+        self.code = code
+
+
+def library_path():
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Every function include/tfhe_hip.h declares."""
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tfhe_[a-z0-9_]+)\s*\(", text)))
+
+
+def load_library():
+    """Load lib/libtfhe_hip.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TfheError(-3, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(the HIP extension is required; there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    u32p, u8p, f64p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_void_p
+    lib.tfhe_last_error.restype = C.c_char_p
+    sig = {
+        "tfhe_device_count": [C.POINTER(C.c_int)],
+        "tfhe_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(vp)],
+        "tfhe_ctx_destroy": [vp],
+        "tfhe_ctx_params": [vp, C.POINTER(Params)],
+        "tfhe_ctx_sync": [vp],
+        "tfhe_load_bsk_fourier": [vp, f64p],
+        "tfhe_load_bsk_torus": [vp, u32p],
+        "tfhe_load_ksk": [vp, u32p],
+        "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
+        "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
+        "tfhe_blind_rotate_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int, C.c_int],
+        "tfhe_blind_rotate_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp],
+        "tfhe_external_product_batch": [vp, C.c_int, u32p, u32p, C.c_int],
+        "tfhe_extract_keyswitch_batch": [vp, u32p, u32p, C.c_int],
+        "tfhe_extract_keyswitch_batch_dev": [vp, vp, vp, C.c_int, vp],
+        "tfhe_gate_batch": [vp, u8p, C.c_int, u32p, u32p, u32p, u32p, C.c_int],
+        "tfhe_gate_batch_dev": [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp],
+        "tfhe_to_fourier_batch": [vp, u32p, f64p, C.c_int],
+        "tfhe_to_poly_batch": [vp, f64p, u32p, C.c_int],
+        "tfhe_last_kernel_ms": [vp, C.c_int, C.POINTER(C.c_float)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    lib = load_library()
+    return [s for s in declared_symbols() if hasattr(lib, s)]
+
+
+def _u32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def _p32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32)) if a is not None else None
+
+
+def _devptr(t):
+    """Device pointer of a torch tensor (or a raw int / None)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("device variants need contiguous GPU tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One GPU context = evaluator.Evaluator + the loaded cloud key (single submitter)."""
+
+    def __init__(self, params, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.params = params
+        self._check(self._lib.tfhe_ctx_create(C.byref(params), int(device), C.byref(self._h)))
+        self.device = device
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TfheError(rc, self._lib.tfhe_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.tfhe_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- keys
+    def load_bsk_fourier(self, bsk):
+        p = self.params
+        bsk = np.ascontiguousarray(bsk, dtype=np.float64)
+        if bsk.shape != (p.n, 2 * p.L, 2, p.N):
+            raise ValueError(f"bsk shape {bsk.shape}")
+        self._check(self._lib.tfhe_load_bsk_fourier(self._h, bsk.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def load_bsk_torus(self, bsk):
+        p = self.params
+        bsk = _u32(bsk, (p.n, 2 * p.L, 2, p.N))
+        self._check(self._lib.tfhe_load_bsk_torus(self._h, _p32(bsk)))
+
+    def load_ksk(self, ksk):
+        p = self.params
+        ksk = _u32(ksk, (p.ksk_rows, p.n + 1))
+        self._check(self._lib.tfhe_load_ksk(self._h, _p32(ksk)))
+
+    # ---- host-pointer entry points
+    def _tv(self, tv, B):
+        p = self.params
+        if tv is None:
+            return None, 0
+        tv = _u32(tv)
+        if tv.shape == (2, p.N):
+            return tv, 0
+        if tv.shape == (B, 2, p.N):
+            return tv, 1
+        raise ValueError(f"testvec shape {tv.shape}")
+
+    def bootstrap_batch(self, cts, testvec=None):
+        p = self.params
+        cts = _u32(cts)
+        B = cts.shape[0]
+        if cts.shape != (B, p.n + 1):
+            raise ValueError(f"ciphertext shape {cts.shape}")
+        tv, per = self._tv(testvec, B)
+        out = np.empty_like(cts)
+        self._check(self._lib.tfhe_bootstrap_batch(self._h, _p32(cts), _p32(tv), per, _p32(out), B))
+        return out
+
+    def blind_rotate_batch(self, cts, testvec=None, nsteps=-1):
+        p = self.params
+        cts = _u32(cts)
+        B = cts.shape[0]
+        if cts.shape != (B, p.n + 1):
+            raise ValueError(f"ciphertext shape {cts.shape}")
+        tv, per = self._tv(testvec, B)
+        out = np.empty((B, 2, p.N), np.uint32)
+        self._check(self._lib.tfhe_blind_rotate_batch(self._h, _p32(cts), _p32(tv), per, _p32(out), B, int(nsteps)))
+        return out
+
+    def external_product_batch(self, key_index, trlwe):
+        p = self.params
+        trlwe = _u32(trlwe)
+        B = trlwe.shape[0]
+        if trlwe.shape != (B, 2, p.N):
+            raise ValueError(f"trlwe shape {trlwe.shape}")
+        out = np.empty_like(trlwe)
+        self._check(self._lib.tfhe_external_product_batch(self._h, int(key_index), _p32(trlwe), _p32(out), B))
+        return out
+
+    def extract_keyswitch_batch(self, trlwe):
+        p = self.params
+        trlwe = _u32(trlwe)
+        B = trlwe.shape[0]
+        if trlwe.shape != (B, 2, p.N):
+            raise ValueError(f"trlwe shape {trlwe.shape}")
+        out = np.empty((B, p.n + 1), np.uint32)
+        self._check(self._lib.tfhe_extract_keyswitch_batch(self._h, _p32(trlwe), _p32(out), B))
+        return out
+
+    def gate_batch(self, ops, a, b, c=None):
+        p = self.params
+        a, b = _u32(a), _u32(b)
+        B = a.shape[0]
+        if a.shape != (B, p.n + 1) or b.shape != a.shape:
+            raise ValueError(f"operand shapes {a.shape} {b.shape}")
+        c = _u32(c, a.shape) if c is not None else None
+        out = np.empty_like(a)
+        if isinstance(ops, str):
+            opp, uni = None, OPS[ops]
+        else:
+            opa = np.ascontiguousarray(ops, dtype=np.uint8)
+            if opa.shape != (B,):
+                raise ValueError(f"ops shape {opa.shape}")
+            opp, uni = opa.ctypes.data_as(C.POINTER(C.c_uint8)), -1
+        self._check(self._lib.tfhe_gate_batch(self._h, opp, uni, _p32(a), _p32(b), _p32(c), _p32(out), B))
+        return out
+
+    def to_fourier_batch(self, polys):
+        polys = _u32(polys)
+        P, N = polys.shape
+        out = np.empty((P, N), np.float64)
+        self._check(self._lib.tfhe_to_fourier_batch(self._h, _p32(polys), out.ctypes.data_as(C.POINTER(C.c_double)), P))
+        return out
+
+    def to_poly_batch(self, spectra):
+        spectra = np.ascontiguousarray(spectra, dtype=np.float64)
+        P, N = spectra.shape
+        out = np.empty((P, N), np.uint32)
+        self._check(self._lib.tfhe_to_poly_batch(self._h, spectra.ctypes.data_as(C.POINTER(C.c_double)), _p32(out), P))
+        return out
+
+    # ---- device-pointer entry points (torch tensors; stream = torch.cuda.Stream or None)
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            return None
+        return C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+
+    def gate_batch_dev(self, ops, a, b, c, out, stream=None):
+        B = a.shape[0]
+        if isinstance(ops, str):
+            opp, uni = None, OPS[ops]
+        else:
+            opp, uni = _devptr(ops), -1
+        self._check(self._lib.tfhe_gate_batch_dev(self._h, opp, uni, _devptr(a), _devptr(b), _devptr(c), _devptr(out),
+                                                  B, self._stream(stream)))
+
+    def bootstrap_batch_dev(self, cts, testvec, out, stream=None):
+        B = cts.shape[0]
+        per = 1 if (testvec is not None and testvec.dim() == 3) else 0
+        self._check(self._lib.tfhe_bootstrap_batch_dev(self._h, _devptr(cts), _devptr(testvec), per, _devptr(out), B,
+                                                       self._stream(stream)))
+
+    def blind_rotate_batch_dev(self, cts, testvec, out, nsteps=-1, stream=None):
+        B = cts.shape[0]
+        per = 1 if (testvec is not None and testvec.dim() == 3) else 0
+        self._check(self._lib.tfhe_blind_rotate_batch_dev(self._h, _devptr(cts), _devptr(testvec), per, _devptr(out),
+                                                          B, int(nsteps), self._stream(stream)))
+
+    def extract_keyswitch_batch_dev(self, trlwe, out, stream=None):
+        B = trlwe.shape[0]
+        self._check(self._lib.tfhe_extract_keyswitch_batch_dev(self._h, _devptr(trlwe), _devptr(out), B,
+                                                               self._stream(stream)))
+
+    def sync(self):
+        self._check(self._lib.tfhe_ctx_sync(self._h))
+
+    def last_kernel_ms(self, which=0):
+        ms = C.c_float()
+        self._check(self._lib.tfhe_last_kernel_ms(self._h, int(which), C.byref(ms)))
+        return ms.value

@@ -1,0 +1,24 @@
+"""cloudkey.CloudKey (cloudkey/cloudkey.go:16-31) as a GPU-resident object.
+
+The reference's CloudKey holds {DecompositionOffset, BlindRotateTestvec, KeySwitchingKey,
+BootstrappingKey} as Go pointer graphs.  Here the same four things live on one GPU inside a
+Context: offset and gate test vector are derived from the parameters at context creation, the
+two keys are uploaded once from flat arrays (what a cgo shim would flatten them to).
+Key GENERATION stays with the caller (it needs the secret key).
+"""
+from ._binding import Context
+
+
+class CloudKey:
+    def __init__(self, params, bsk_fourier=None, bsk_torus=None, ksk=None, device=0):
+        self.params = params
+        self.ctx = Context(params, device)
+        if bsk_fourier is not None:
+            self.ctx.load_bsk_fourier(bsk_fourier)
+        elif bsk_torus is not None:
+            self.ctx.load_bsk_torus(bsk_torus)
+        if ksk is not None:
+            self.ctx.load_ksk(ksk)
+
+    def close(self):
+        self.ctx.close()

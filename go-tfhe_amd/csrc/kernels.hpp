@@ -1,0 +1,431 @@
+// kernels.hpp -- HIP kernels of the gate-bootstrap path (gfx950 / CDNA4).
+//
+//   k_blind_rotate        evaluator.BlindRotateAssign (evaluator.go:110-135) with the gate's
+//                         linear preparation (gates_helper.go:10-63) and the mod-switch fused
+//                         into its prologue.  One workgroup = one bootstrap, two wavefronts:
+//                         wave 0 owns accumulator polynomial A, wave 1 owns B.  The n CMUX
+//                         steps run inside the kernel with the accumulator resident in
+//                         registers + LDS; only the bootstrapping key is streamed.
+//   k_external_product    evaluator.ExternalProductAssign (evaluator.go:50-81), same core.
+//   k_extract_keyswitch   trlwe.SampleExtractIndexAssign + trgsw.IdentityKeySwitchingAssign
+//                         (trlwe_ops.go:10-21, keyswitch.go:10-37).
+//   k_bsk_from_fourier / k_bsk_from_torus / k_ksk_pack   key ingestion into device layouts.
+//   k_to_fourier / k_to_poly                              FFT test seams.
+#pragma once
+
+#include "negacyclic_fft.hpp"
+
+namespace tfhe {
+
+// ------------------------------------------------------------------------------------
+// Device layouts
+//
+// Bootstrapping key (wave-native): cd bsk[n][2][L][2][8][64]
+//     [i]     LWE index / CMUX step
+//     [p]     which wave consumes it: p = 0 rows of the A digits, p = 1 rows of the B digits
+//             (reference row r = p*L + l, trgsw.go:51-54 / evaluator.go:59-61)
+//     [l]     gadget level
+//     [part]  0 = A spectrum of the row, 1 = B spectrum
+//     [reg][lane]  spectrum order of fft512_forward; one (reg) slice = 64 lanes x 16 B = 1 KiB,
+//             so every key load is one fully coalesced global_load_dwordx4 per wave.
+//     Same byte count as the reference's [n][2L][2][N] float64 (68,812,800 B at 128-bit).
+//
+// Key-switching key (packed): uint32 ksk[N][t][base-1][n1p], n1p = (n+1) rounded up to 4 words.
+//     The k = 0 rows of the reference table are all-zero and never read (keyswitch.go:30),
+//     so they are not stored; rows are padded so each lane can fetch 16 B aligned.
+// ------------------------------------------------------------------------------------
+
+__host__ __device__ __forceinline__ size_t bsk_index(int L, int i, int p, int l, int part, int reg, int lane)
+{
+    return ((((size_t)(i * 2 + p) * L + l) * 2 + part) * 8 + reg) * 64 + lane;
+}
+
+// Gate linear preparation: out = sa*a + sb*b, body += cst (gates_helper.go:10-63,
+// gates.go:52-104).  XNOR uses the scalar gate's +1/4 (gates.go:56).
+struct GateCoef {
+    uint32_t sa, sb, cst;
+};
+
+__host__ __device__ __forceinline__ GateCoef gate_coef(int op)
+{
+    const uint32_t E = 0x20000000u, Q = 0x40000000u, m1 = 0xFFFFFFFFu;
+    switch (op) {
+    case 0: return {m1, m1, E};          // NAND  -(a+b) + 1/8
+    case 1: return {1u, 1u, 0u - E};     // AND    a+b   - 1/8
+    case 2: return {1u, 1u, E};          // OR     a+b   + 1/8
+    case 3: return {1u, 2u, Q};          // XOR    a+2b  + 1/4
+    case 4: return {1u, 0u - 2u, Q};     // XNOR   a-2b  + 1/4
+    case 5: return {m1, m1, 0u - E};     // NOR   -(a+b) - 1/8
+    case 6: return {m1, 1u, 0u - E};     // ANDNY -a+b   - 1/8
+    case 7: return {1u, m1, 0u - E};     // ANDYN  a-b   - 1/8
+    case 8: return {m1, 1u, E};          // ORNY  -a+b   + 1/8
+    case 9: return {1u, m1, E};          // ORYN   a-b   + 1/8
+    default: return {1u, 0u, 0u};        // plain: ct = a
+    }
+}
+
+struct BlindRotateArgs {
+    const cd *bsk;          // device layout above
+    const cd *tw;           // twiddle table (negacyclic_fft.hpp)
+    const uint32_t *in0;    // [B][n+1]
+    const uint32_t *in1;    // [B][n+1] or nullptr (plain bootstrap)
+    const uint8_t *ops;     // [B] or nullptr
+    int op_uniform;         // used when ops == nullptr; < 0 = plain (ct = in0)
+    const uint32_t *tv;     // [2][N] or [B][2][N]
+    long tv_stride;         // 0 or 2N
+    uint32_t *out;          // [B][2][N]
+    int n, nsteps, Nbit;
+    uint32_t offset;        // decomposition offset (cloudkey.go:60-71)
+};
+
+constexpr int kMaxLweDim = 1088;
+
+// One CMUX "core": given the difference polynomial d (this wave's half, 16 coefficients per
+// lane: q < 8 -> j = 64q+lane, q >= 8 -> j = 64(q-8)+lane+512), produce this wave's half of
+// bsk[i] (x) d as 16 torus words.  Two waves cooperate: each transforms the L digit
+// polynomials of its own half, multiplies them with its L key rows into partial sums for
+// BOTH outputs, hands the partner's partial sum over through LDS, and inverse-transforms
+// its own.  (evaluator.go:50-81; decomposer.go:55-66; fourier_ops.go:167-191)
+template <int L, int BGBIT>
+__device__ __forceinline__ void external_product_core(const uint32_t (&d)[16], uint32_t (&e)[16],
+                                                      const cd *__restrict__ key_ip, /* &bsk[i][p] */
+                                                      cd *sc_mine, const cd *sc_other,
+                                                      const cd *__restrict__ table, const LaneTwiddles &tw,
+                                                      uint32_t offset, int p, int lane)
+{
+    cd keep[8], send[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) keep[k] = send[k] = cd{0.0, 0.0};
+
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+        cd x[8];
+        constexpr uint32_t mask = (1u << BGBIT) - 1u;
+        constexpr int half = 1 << (BGBIT - 1);
+        const int shift = 32 - (l + 1) * BGBIT;
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            int dr = (int)(((d[a] + offset) >> shift) & mask) - half;
+            int di = (int)(((d[a + 8] + offset) >> shift) & mask) - half;
+            x[a] = cd{(double)dr, (double)di};
+        }
+        fft512_forward(x, sc_mine, table, tw, lane);
+        const cd *kA = key_ip + (size_t)(l * 2 + 0) * 512 + lane;
+        const cd *kB = key_ip + (size_t)(l * 2 + 1) * 512 + lane;
+        // wave p keeps output p: for p = 0 "keep" accumulates the A output, for p = 1 the B output
+        const cd *kKeep = p ? kB : kA;
+        const cd *kSend = p ? kA : kB;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            cfma(keep[k], x[k], kKeep[k * 64]);
+            cfma(send[k], x[k], kSend[k * 64]);
+        }
+    }
+    // hand the partner's partial sum over
+#pragma unroll
+    for (int k = 0; k < 8; k++) sc_mine[k * 64 + lane] = send[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
+    __syncthreads();
+    fft512_inverse(keep, sc_mine, table, tw, lane);
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        e[a] = round_to_torus_small(keep[a].re);
+        e[a + 8] = round_to_torus_small(keep[a].im);
+    }
+}
+
+template <int L, int BGBIT>
+__global__ __launch_bounds__(128) void k_blind_rotate(BlindRotateArgs A)
+{
+    constexpr int N = 1024;
+    __shared__ cd sc[2][kScratchSlots];
+    __shared__ uint32_t accL[2][N];
+    __shared__ uint16_t abarL[kMaxLweDim];
+    __shared__ int btL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x;
+    const int n = A.n;
+
+    // ---- gate linear prep + mod-switch (gates_helper.go:10-63, evaluator.go:116,122)
+    {
+        const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
+        const GateCoef g = gate_coef(A.in1 ? op : -1);
+        const uint32_t *x0 = A.in0 + (size_t)item * (n + 1);
+        const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
+        const int sh = 32 - A.Nbit - 1;
+        const uint32_t rnd = 1u << (sh - 1);
+        for (int x = tid; x <= n; x += 128) {
+            uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
+            if (x == n) {
+                v += g.cst;
+                // int add, no 32-bit wrap (evaluator.go:116)
+                btL = 2 * N - (int)(((unsigned long long)v + rnd) >> sh);
+            } else {
+                abarL[x] = (uint16_t)((uint32_t)(v + rnd) >> sh);   // wraps (evaluator.go:122)
+            }
+        }
+    }
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, A.tw, lane);
+    __syncthreads();
+
+    // ---- acc = X^bt * testvec  (evaluator.go:117-118, buffer_methods.go:133-164)
+    uint32_t acc[16];
+    {
+        const int bt = btL & (2 * N - 1);
+        const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int j = 64 * q + lane;
+            const int s = (j - bt) & (2 * N - 1);
+            uint32_t v = tv[s & (N - 1)];
+            v ^= 0u - (uint32_t)((s >> 10) & 1);      // "negation" is the bitwise complement
+            acc[q] = v;
+            accL[p][j] = v;
+        }
+    }
+    wave_lds_order();
+
+    const cd *key = A.bsk + (size_t)p * L * 2 * 512;
+    const int nsteps = A.nsteps;
+    for (int i = 0; i < nsteps; i++) {
+        const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        // d = X^at * acc - acc   (evaluator.go:122-126, 93-96)
+        uint32_t d[16], e[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int j = 64 * q + lane;
+            const int s = (j - at) & (2 * N - 1);
+            uint32_t v = accL[p][s & (N - 1)];
+            v ^= 0u - (uint32_t)((s >> 10) & 1);
+            d[q] = v - acc[q];
+        }
+        external_product_core<L, BGBIT>(d, e, key + (size_t)i * 2 * L * 2 * 512, sc[p], sc[p ^ 1], A.tw, tw,
+                                        A.offset, p, lane);
+        // acc += e   (evaluator.go:102-105)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            acc[q] += e[q];
+            accL[p][64 * q + lane] = acc[q];
+        }
+        wave_lds_order();
+    }
+
+    uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
+#pragma unroll
+    for (int q = 0; q < 16; q++) out[64 * q + lane] = acc[q];
+}
+
+// ExternalProductAssign of in[b] with bsk[key_index] (test seam).
+template <int L, int BGBIT>
+__global__ __launch_bounds__(128) void k_external_product(const cd *bsk, const cd *twt, int key_index,
+                                                           const uint32_t *in, uint32_t *out, uint32_t offset)
+{
+    constexpr int N = 1024;
+    __shared__ cd sc[2][kScratchSlots];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, twt, lane);
+    const uint32_t *src = in + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
+    uint32_t d[16], e[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) d[q] = src[64 * q + lane];
+    const cd *key = bsk + ((size_t)key_index * 2 + p) * L * 2 * 512;
+    external_product_core<L, BGBIT>(d, e, key, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
+    uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
+#pragma unroll
+    for (int q = 0; q < 16; q++) dst[64 * q + lane] = e[q];
+}
+
+// ------------------------------------------------------------------------------------
+// Key ingestion
+// ------------------------------------------------------------------------------------
+
+// Reference Fourier layout [n][2L][2][N] float64 -> device layout.  One thread per complex.
+__global__ void k_bsk_from_fourier(const double *__restrict__ src, cd *__restrict__ dst, int n, int L)
+{
+    const size_t total = (size_t)n * 2 * L * 2 * 512;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, reg = (idx >> 6) & 7, part = (idx >> 9) & 1;
+    size_t rest = idx >> 10;
+    const int l = rest % L; rest /= L;
+    const int p = rest & 1;
+    const int i = (int)(rest >> 1);
+    const int r = p * L + l;
+    const double *poly = src + (((size_t)i * 2 * L + r) * 2 + part) * 1024;
+    const int s = reference_slot_1024(reg, lane);
+    const int base = 8 * (s >> 2) + (s & 3);
+    dst[idx] = cd{poly[base], poly[base + 4]};
+}
+
+// Coefficient-domain key [n][2L][2][N] uint32 -> device layout (own forward FFT; replaces
+// trgsw.NewTRGSWLv1FFT, trgsw.go:71-82).  One wave per polynomial.
+__global__ __launch_bounds__(64) void k_bsk_from_torus(const uint32_t *__restrict__ src, cd *__restrict__ dst,
+                                                        const cd *__restrict__ twt, int L)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x;
+    const int polyIdx = blockIdx.x;                       // ((i*2L + r)*2 + part)
+    const int part = polyIdx & 1, r = (polyIdx >> 1) % (2 * L), i = (polyIdx >> 1) / (2 * L);
+    const int p = r / L, l = r % L;
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, twt, lane);
+    const uint32_t *poly = src + (size_t)polyIdx * 1024;
+    cd x[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+        x[a] = cd{(double)(int32_t)poly[64 * a + lane], (double)(int32_t)poly[64 * a + lane + 512]};
+    fft512_forward(x, sc, twt, tw, lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[bsk_index(L, i, p, l, part, k, lane)] = x[k];
+}
+
+// Reference KSK [N*t*base][n+1] -> packed [N*t*(base-1)][n1p] (drops the all-zero k = 0 rows).
+__global__ void k_ksk_pack(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n1, int n1p,
+                           int base, size_t rows_packed)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows_packed * (size_t)n1p) return;
+    const size_t row = idx / n1p;
+    const int x = (int)(idx % n1p);
+    const size_t ij = row / (base - 1);
+    const int k = (int)(row % (base - 1)) + 1;
+    dst[idx] = x < n1 ? src[(ij * base + k) * (size_t)n1 + x] : 0u;
+}
+
+// ------------------------------------------------------------------------------------
+// Sample extract (index 0) + identity key switch.  One workgroup (4 waves) per ciphertext.
+//   phase 1: all N*t digits are computed and the non-zero ones compacted into an LDS list
+//            (the subtraction is commutative mod 2^32, so order is free);
+//   phase 2: each wave walks a quarter of the list; a wave covers one packed row with
+//            CH coalesced 16-byte loads per lane and keeps CH uint4 partial sums;
+//   phase 3: the four partial sums are combined through LDS.
+// ------------------------------------------------------------------------------------
+struct KeySwitchArgs {
+    const uint32_t *trlwe;   // [B][2][N]
+    const uint32_t *ksk;     // packed
+    uint32_t *out;           // [B][n+1]
+    int n, N, t, basebit, n1p;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
+{
+    __shared__ uint32_t rows[9216];
+    __shared__ uint32_t red[4][CH * 256];
+    __shared__ int count;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int N = A.N, t = A.t, bb = A.basebit, base1 = (1 << bb) - 1;
+    const uint32_t *ta = A.trlwe + (size_t)blockIdx.x * 2 * N;
+    if (tid == 0) count = 0;
+    __syncthreads();
+    const uint32_t prec = 1u << (32 - (1 + bb * t));
+    for (int idx = tid; idx < N * t; idx += 256) {
+        const int i = idx / t, j = idx - i * t;
+        // SampleExtractIndexAssign(.,0,.): P[0] = A[0], P[i] = ~A[N-i]  (trlwe_ops.go:13-19)
+        const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
+        const uint32_t k = ((ai + prec) >> (32 - (j + 1) * bb)) & (uint32_t)base1;
+        if (k) rows[atomicAdd(&count, 1)] = (uint32_t)idx * base1 + (k - 1);
+    }
+    __syncthreads();
+    const int cnt = count;
+    uint4 acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) acc[c] = make_uint4(0, 0, 0, 0);
+    const int quads = A.n1p >> 2;
+    for (int e = w; e < cnt; e += 4) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(A.ksk + (size_t)rows[e] * A.n1p);
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int qd = c * 64 + lane;
+            if (qd < quads) {
+                const uint4 v = row[qd];
+                acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        uint32_t *r = &red[w][(c * 64 + lane) * 4];
+        r[0] = acc[c].x; r[1] = acc[c].y; r[2] = acc[c].z; r[3] = acc[c].w;
+    }
+    __syncthreads();
+    uint32_t *out = A.out + (size_t)blockIdx.x * (A.n + 1);
+    for (int x = tid; x <= A.n; x += 256) {
+        const uint32_t sum = red[0][x] + red[1][x] + red[2][x] + red[3][x];
+        out[x] = (x == A.n ? ta[N] : 0u) - sum;      // out = (0,...,0,b) - sum rows (keyswitch.go:18-33)
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// FFT test seams, spectra in the reference FourierPoly layout.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_to_fourier(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
+                                                    const cd *__restrict__ twt)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x;
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, twt, lane);
+    const uint32_t *poly = polys + (size_t)blockIdx.x * 1024;
+    double *fp = spectra + (size_t)blockIdx.x * 1024;
+    cd x[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+        x[a] = cd{(double)(int32_t)poly[64 * a + lane], (double)(int32_t)poly[64 * a + lane + 512]};
+    fft512_forward(x, sc, twt, tw, lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int s = reference_slot_1024(k, lane), base = 8 * (s >> 2) + (s & 3);
+        fp[base] = x[k].re;
+        fp[base + 4] = x[k].im;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_to_poly(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
+                                                 const cd *__restrict__ twt)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x;
+    LaneTwiddles tw;
+    load_lane_twiddles(tw, twt, lane);
+    const double *fp = spectra + (size_t)blockIdx.x * 1024;
+    uint32_t *poly = polys + (size_t)blockIdx.x * 1024;
+    cd x[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int s = reference_slot_1024(k, lane), base = 8 * (s >> 2) + (s & 3);
+        x[k] = cd{fp[base], fp[base + 4]};
+    }
+    fft512_inverse(x, sc, twt, tw, lane);
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        poly[64 * a + lane] = round_to_torus_wide(x[a].re);
+        poly[64 * a + lane + 512] = round_to_torus_wide(x[a].im);
+    }
+}
+
+// Small helpers for the MUX composition (gates.go:107-114): gather / scatter LWE samples.
+__global__ void k_gather_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
+                              int n1, int count)
+{
+    const int r = blockIdx.x;
+    if (r >= count) return;
+    for (int x = threadIdx.x; x < n1; x += blockDim.x) dst[(size_t)r * n1 + x] = src[(size_t)idx[r] * n1 + x];
+}
+
+__global__ void k_scatter_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
+                               int n1, int count)
+{
+    const int r = blockIdx.x;
+    if (r >= count) return;
+    for (int x = threadIdx.x; x < n1; x += blockDim.x) dst[(size_t)idx[r] * n1 + x] = src[(size_t)r * n1 + x];
+}
+
+} // namespace tfhe

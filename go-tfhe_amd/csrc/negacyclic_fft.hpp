@@ -1,0 +1,195 @@
+// negacyclic_fft.hpp -- one-wavefront negacyclic FFT over Z[X]/(X^N+1) for gfx950.
+//
+// Replaces poly.Evaluator.ToFourierPolyAssign / ToPolyAssignUnsafe of the reference
+// (poly/fourier_transform.go:18-21,40-44,178-347).  The reference folds N real
+// coefficients into M = N/2 complex points z_j = p_j + i p_{j+M} and evaluates
+// Z(X) = sum z_j X^j at the M roots w of X^M = i, i.e. w = zeta^(1+4u), zeta = exp(i pi/N),
+// u in Z_M, with a radix-2 scalar loop.  Here ONE 64-lane wavefront owns the whole
+// transform with R = M/64 complex points per lane and walks the same root tree in
+// radix-8 levels (polynomial remaindering mod X^64 - rho, X^8 - sigma, X - w), each
+// level being "pre-twist by a unit root, then an 8-point DFT held in registers":
+//
+//   N = 1024:           level 1 (a -> m)   exchange   level 2 (b -> m')   exchange   level 3 (c -> m'')
+//   point j = 64a+8b+c  reg a, lane 8b+c    --LDS-->   reg b, lane 8m+c    --LDS-->   reg c, lane 8m+m'
+//
+// and the value left in (reg m'', lane 8m+m') is Z(zeta^(1+4u)), u = m + 8m' + 64m''.
+// The spectrum stays in that order: pointwise products do not care, and the
+// bootstrapping key is stored in the same order (bsk_index()).  The two lane<->register
+// exchanges go through a per-wave LDS scratch with conflict-free padded strides; they
+// need no s_barrier because a wave's DS operations execute in issue order.
+//
+// N = 2048 (Uint5) adds one radix-2 level in registers in front (X^1024 - i splits into
+// X^512 -+ exp(i pi/4)) and then runs the two halves as independent 512-point trees.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfhe {
+
+struct __attribute__((aligned(16))) cd {
+    double re, im;
+};
+
+__device__ __forceinline__ cd operator+(cd a, cd b) { return {a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cd operator-(cd a, cd b) { return {a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cd cmul(cd a, cd b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+// a * conj(b)
+__device__ __forceinline__ cd cmulc(cd a, cd b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }
+__device__ __forceinline__ void cfma(cd &acc, cd a, cd b)
+{
+    acc.re = fma(a.re, b.re, fma(-a.im, b.im, acc.re));
+    acc.im = fma(a.re, b.im, fma(a.im, b.re, acc.im));
+}
+// a * (S*i)
+template <int S> __device__ __forceinline__ cd mul_i(cd a) { return S > 0 ? cd{-a.im, a.re} : cd{a.im, -a.re}; }
+
+// y_k = sum_n x_n exp(S * 2 pi i n k / 8), in place, natural order in and out.
+template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
+{
+    constexpr double h = 0.70710678118654752440;
+    cd b0 = x[0] + x[4], b1 = x[1] + x[5], b2 = x[2] + x[6], b3 = x[3] + x[7];
+    cd d0 = x[0] - x[4], t1 = x[1] - x[5], t2 = x[2] - x[6], t3 = x[3] - x[7];
+    cd d1 = S > 0 ? cd{(t1.re - t1.im) * h, (t1.im + t1.re) * h} : cd{(t1.re + t1.im) * h, (t1.im - t1.re) * h};
+    cd d2 = mul_i<S>(t2);
+    cd d3 = S > 0 ? cd{(-t3.re - t3.im) * h, (t3.re - t3.im) * h} : cd{(t3.im - t3.re) * h, (-t3.im - t3.re) * h};
+    cd e0 = b0 + b2, e1 = b1 + b3, e2 = b0 - b2, e3 = mul_i<S>(b1 - b3);
+    x[0] = e0 + e1; x[4] = e0 - e1; x[2] = e2 + e3; x[6] = e2 - e3;
+    cd f0 = d0 + d2, f1 = d1 + d3, f2 = d0 - d2, f3 = mul_i<S>(d1 - d3);
+    x[1] = f0 + f1; x[5] = f0 - f1; x[3] = f2 + f3; x[7] = f2 - f3;
+}
+
+// A wave's DS operations are executed in issue order, so a wave-private LDS exchange only
+// needs the compiler kept from reordering/merging the accesses.
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Per-wave exchange scratch: 8 rows of 72 sixteen-byte slots (64 used + 8 pad).  With this
+// stride both exchange patterns are conflict-free for ds_write_b128 (8 contiguous lanes ->
+// 8 contiguous slots) and ds_read_b128 (the four 16-lane service groups each touch 16
+// distinct slot residues mod 16).
+constexpr int kScratchSlots = 8 * 72;
+
+// Twiddle table layout (built on the host in long double, tfhe_hip.cpp):
+//   [0..7]                 level-1 pre-twists      c1[a]  = zeta^(64 a)          (wave-uniform)
+//   [8..15]                inverse level-1 factors conj(c1[a]) / 512
+//   [16 + b*64 + lane]     level-2 pre-twists      c2 = zeta^(8 b (1+4m)),        m = lane>>3
+//   [16 + 512 + c*64+lane] level-3 pre-twists      c3 = zeta^(c (1+4(m+8m'))),    m' = lane&7
+constexpr int kTwLevel2 = 16;
+constexpr int kTwLevel3 = 16 + 512;
+constexpr int kTwCount1024 = 16 + 1024;
+
+// Per-lane twiddles kept in VGPRs for the life of a kernel (b, c = 1..7; index 0 unused).
+struct LaneTwiddles {
+    cd t2[8];
+    cd t3[8];
+};
+
+__device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &tw, const cd *__restrict__ table, int lane)
+{
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+        tw.t2[k] = table[kTwLevel2 + k * 64 + lane];
+        tw.t3[k] = table[kTwLevel3 + k * 64 + lane];
+    }
+    tw.t2[0] = tw.t3[0] = cd{1.0, 0.0};
+}
+
+// Index u of the root zeta^(1+4u) held by (reg, lane) after the forward transform.
+__host__ __device__ __forceinline__ int spectrum_u_1024(int reg, int lane) { return (lane >> 3) + 8 * (lane & 7) + 64 * reg; }
+
+// Slot of that root in the reference's FourierPoly order: slot s holds
+// P(zeta^(1 - 4 bitrev9(s))) (fourier_transform.go:178-247 with the twiddles of
+// poly_evaluator.go:114-133), so s = bitrev9(-u mod 512).
+__host__ __device__ __forceinline__ int reference_slot_1024(int reg, int lane)
+{
+    int v = (512 - spectrum_u_1024(reg, lane)) & 511, s = 0;
+#pragma unroll
+    for (int b = 0; b < 9; b++) s |= ((v >> b) & 1) << (8 - b);
+    return s;
+}
+
+// Forward transform of 512 complex points; x[a] = z_{64a+lane} in, spectrum order out.
+__device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__restrict__ table,
+                                               const LaneTwiddles &tw, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+    for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
+    dft8<1>(x);
+    // exchange 1: (reg m, lane 8b+c) -> (reg b, lane 8m+c)
+#pragma unroll
+    for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];
+    wave_lds_order();
+#pragma unroll
+    for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
+    wave_lds_order();
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tw.t2[b]);
+    dft8<1>(x);
+    // exchange 2: (reg m', lane 8m+c) -> (reg c, lane 8m+m')
+#pragma unroll
+    for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];
+    wave_lds_order();
+#pragma unroll
+    for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
+    wave_lds_order();
+#pragma unroll
+    for (int c = 1; c < 8; c++) x[c] = cmul(x[c], tw.t3[c]);
+    dft8<1>(x);
+}
+
+// Inverse transform (includes the 1/512 scale); spectrum order in, x[a] = z_{64a+lane} out.
+__device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__restrict__ table,
+                                               const LaneTwiddles &tw, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    dft8<-1>(x);
+#pragma unroll
+    for (int c = 1; c < 8; c++) x[c] = cmulc(x[c], tw.t3[c]);
+    // (reg c, lane 8m+m') -> (reg m', lane 8m+c)
+#pragma unroll
+    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    wave_lds_order();
+#pragma unroll
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    wave_lds_order();
+    dft8<-1>(x);
+#pragma unroll
+    for (int b = 1; b < 8; b++) x[b] = cmulc(x[b], tw.t2[b]);
+    // (reg b, lane 8m+c) -> (reg m, lane 8b+c)
+#pragma unroll
+    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    wave_lds_order();
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    wave_lds_order();
+    dft8<-1>(x);
+#pragma unroll
+    for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
+}
+
+// Nearest integer of v, reduced mod 2^32.  Replaces floatModQInPlace + the uint32(int64())
+// conversion of the reference (fourier_transform.go:88-125).  Adding 1.5*2^52 leaves the
+// rounded integer in the low mantissa bits (two's complement), valid for |v| < 2^51; the
+// N=1024 sets are bounded by 2L*N*(Bg/2)*2^31 = 2^48.6.  (Go's math.Round rounds halves
+// away from zero, this rounds them to even; a half can only occur once the FFT error
+// reaches 0.5, where the reference itself is no longer exact -- SURVEY.md appendix A.)
+__device__ __forceinline__ uint32_t round_to_torus_small(double v)
+{
+    return (uint32_t)__double2loint(v + 6755399441055744.0);
+}
+
+// General form for |v| up to 2^62 (Uint5: values reach ~2^58).
+__device__ __forceinline__ uint32_t round_to_torus_wide(double v)
+{
+    double r = rint(v);
+    double t = r - 4294967296.0 * floor(r * (1.0 / 4294967296.0));
+    return (uint32_t)t;
+}
+
+} // namespace tfhe

@@ -1,0 +1,565 @@
+// tfhe_hip.hip -- C ABI (include/tfhe_hip.h) over the HIP kernels in kernels.hpp.
+//
+// Host-side glue only: context/key residency, staging buffers, launches, HIP-event timing.
+// There is NO CPU fallback: every entry point either runs the gfx950 kernels or fails with a
+// TFHE_E_* code.
+#include "../../include/tfhe_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace tfhe;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(TFHE_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return TFHE_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        cap = bytes;
+        return TFHE_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+} // namespace
+
+struct tfhe_ctx {
+    tfhe_params P{};
+    int device = 0;
+    int shape = 0;              // 1: N=1024,L=3,Bgbit=6   2: N=2048,L=1,Bgbit=22
+    uint32_t offset = 0;        // cloudkey.go:60-71
+    int n1p = 0;                // padded LWE row length of the packed KSK
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool ev_valid[2] = {false, false};
+    DevBuf bsk, ksk, tw, gate_tv;
+    bool have_bsk = false, have_ksk = false;
+    // staging (grow-only)
+    DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_t0, s_t1, s_t2, s_t3;
+    std::mutex mu;
+};
+
+namespace {
+
+size_t bsk_elems(const tfhe_params &P) { return (size_t)P.n * 2 * P.L * 2 * (P.N / 2); }
+size_t ksk_rows_ref(const tfhe_params &P) { return (size_t)P.N * P.t * (1u << P.basebit); }
+size_t ksk_rows_packed(const tfhe_params &P) { return (size_t)P.N * P.t * ((1u << P.basebit) - 1); }
+
+hipStream_t pick(tfhe_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+// Twiddle table for N = 1024 (negacyclic_fft.hpp), computed in long double.
+std::vector<cd> make_twiddles_1024()
+{
+    std::vector<cd> t(kTwCount1024);
+    const long double pi = 3.14159265358979323846264338327950288L;
+    auto zeta = [&](long e) {               // zeta^e, zeta = exp(i pi / 1024)
+        e %= 2048; if (e < 0) e += 2048;
+        long double a = pi * (long double)e / 1024.0L;
+        return cd{(double)cosl(a), (double)sinl(a)};
+    };
+    for (int a = 0; a < 8; a++) {
+        t[a] = zeta(64L * a);
+        cd c = zeta(-64L * a);
+        t[8 + a] = cd{c.re / 512.0, c.im / 512.0};
+    }
+    for (int k = 0; k < 8; k++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int m = lane >> 3, mp = lane & 7;
+            t[kTwLevel2 + k * 64 + lane] = zeta(8L * k * (1 + 4 * m));
+            t[kTwLevel3 + k * 64 + lane] = zeta((long)k * (1 + 4 * (m + 8 * mp)));
+        }
+    return t;
+}
+
+int check_ctx(tfhe_ctx *c)
+{
+    if (!c) return fail(TFHE_E_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return TFHE_OK;
+}
+
+int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in1, const uint8_t *d_ops,
+                        int op_uniform, const uint32_t *d_tv, int tv_per_item, uint32_t *d_out, int B, int nsteps,
+                        hipStream_t st)
+{
+    if (!c->have_bsk) return fail(TFHE_E_NOKEY, "bootstrapping key not loaded");
+    if (B <= 0) return TFHE_OK;
+    BlindRotateArgs a{};
+    a.bsk = c->bsk.as<cd>();
+    a.tw = c->tw.as<cd>();
+    a.in0 = d_in0; a.in1 = d_in1; a.ops = d_ops; a.op_uniform = op_uniform;
+    a.tv = d_tv ? d_tv : c->gate_tv.as<uint32_t>();
+    a.tv_stride = (d_tv && tv_per_item) ? 2L * c->P.N : 0;
+    a.out = d_out;
+    a.n = c->P.n; a.Nbit = c->P.Nbit;
+    a.nsteps = (nsteps < 0 || nsteps > c->P.n) ? c->P.n : nsteps;
+    a.offset = c->offset;
+    HIP_TRY(hipEventRecord(c->ev[0][0], st));
+    if (c->shape == 1)
+        hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a);
+    else
+        return fail(TFHE_E_INVALID, "parameter shape %d has no blind-rotate kernel", c->shape);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[0][1], st));
+    c->ev_valid[0] = true;
+    return TFHE_OK;
+}
+
+int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int B, hipStream_t st)
+{
+    if (!c->have_ksk) return fail(TFHE_E_NOKEY, "key-switching key not loaded");
+    if (B <= 0) return TFHE_OK;
+    KeySwitchArgs a{};
+    a.trlwe = d_trlwe; a.ksk = c->ksk.as<uint32_t>(); a.out = d_out;
+    a.n = c->P.n; a.N = c->P.N; a.t = c->P.t; a.basebit = c->P.basebit; a.n1p = c->n1p;
+    const int ch = (c->n1p + 255) / 256;
+    HIP_TRY(hipEventRecord(c->ev[1][0], st));
+    switch (ch) {
+    case 1: hipLaunchKernelGGL((k_extract_keyswitch<1>), dim3(B), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_extract_keyswitch<2>), dim3(B), dim3(256), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_extract_keyswitch<3>), dim3(B), dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_extract_keyswitch<4>), dim3(B), dim3(256), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_extract_keyswitch<5>), dim3(B), dim3(256), 0, st, a); break;
+    default: return fail(TFHE_E_INVALID, "LWE dimension %d too large for the key-switch kernel", c->P.n);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1][1], st));
+    c->ev_valid[1] = true;
+    return TFHE_OK;
+}
+
+// Full gate batch on device pointers; handles MUX = OR(AND(a,b), ANDNY(a,c)) (gates.go:107-114:
+// AND(NOT a, c) has exactly ANDNY's linear form -a + c - 1/8).  h_ops may be nullptr.
+int gate_batch_device(tfhe_ctx *c, const uint8_t *d_ops, const uint8_t *h_ops, int op_uniform, const uint32_t *d_a,
+                      const uint32_t *d_b, const uint32_t *d_c, uint32_t *d_out, int B, hipStream_t st)
+{
+    const int n1 = c->P.n + 1;
+    const size_t trl = (size_t)B * 2 * c->P.N * sizeof(uint32_t);
+    std::vector<int> mux;
+    if (d_ops) {
+        for (int i = 0; i < B; i++) {
+            if (h_ops[i] > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d at item %d", h_ops[i], i);
+            if (h_ops[i] == TFHE_OP_MUX) mux.push_back(i);
+        }
+    } else {
+        if (op_uniform < 0 || op_uniform > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d", op_uniform);
+        if (op_uniform == TFHE_OP_MUX) { mux.resize(B); for (int i = 0; i < B; i++) mux[i] = i; }
+    }
+    if (!mux.empty() && !d_c) return fail(TFHE_E_INVALID, "MUX needs the third operand");
+    int rc;
+    if ((rc = c->s_trlwe.reserve(trl))) return rc;
+    // pass A: every item with op' = (MUX ? AND : op) on (a, b)
+    const uint8_t *opsA = d_ops;
+    int uniA = op_uniform;
+    if (!mux.empty()) {
+        if (d_ops) {
+            std::vector<uint8_t> tmp(h_ops, h_ops + B);
+            for (int i : mux) tmp[i] = TFHE_OP_AND;
+            if ((rc = c->s_t3.reserve(B))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->s_t3.p, tmp.data(), B, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));      // tmp goes out of scope
+            opsA = c->s_t3.as<uint8_t>();
+        } else {
+            uniA = TFHE_OP_AND;
+        }
+    }
+    if ((rc = launch_blind_rotate(c, d_a, d_b, opsA, uniA, nullptr, 0, c->s_trlwe.as<uint32_t>(), B, -1, st))) return rc;
+    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), d_out, B, st))) return rc;
+    if (mux.empty()) return TFHE_OK;
+    // pass B: y = ANDNY(a, c) on the MUX items; pass C: out = OR(x, y)
+    const int Mx = (int)mux.size();
+    const size_t rows = (size_t)Mx * n1 * sizeof(uint32_t);
+    if ((rc = c->s_idx.reserve(Mx * sizeof(int)))) return rc;
+    if ((rc = c->s_t0.reserve(rows)) || (rc = c->s_t1.reserve(rows)) || (rc = c->s_t2.reserve(rows))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_idx.p, mux.data(), Mx * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int *d_idx = c->s_idx.as<int>();
+    uint32_t *t0 = c->s_t0.as<uint32_t>(), *t1 = c->s_t1.as<uint32_t>(), *t2 = c->s_t2.as<uint32_t>();
+    hipLaunchKernelGGL(k_gather_rows, dim3(Mx), dim3(256), 0, st, d_a, d_idx, t0, n1, Mx);
+    hipLaunchKernelGGL(k_gather_rows, dim3(Mx), dim3(256), 0, st, d_c, d_idx, t1, n1, Mx);
+    if ((rc = launch_blind_rotate(c, t0, t1, nullptr, TFHE_OP_ANDNY, nullptr, 0, c->s_trlwe.as<uint32_t>(), Mx, -1, st))) return rc;
+    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), t2, Mx, st))) return rc;
+    hipLaunchKernelGGL(k_gather_rows, dim3(Mx), dim3(256), 0, st, (const uint32_t *)d_out, d_idx, t0, n1, Mx);
+    if ((rc = launch_blind_rotate(c, t0, t2, nullptr, TFHE_OP_OR, nullptr, 0, c->s_trlwe.as<uint32_t>(), Mx, -1, st))) return rc;
+    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), t1, Mx, st))) return rc;
+    hipLaunchKernelGGL(k_scatter_rows, dim3(Mx), dim3(256), 0, st, (const uint32_t *)t1, d_idx, d_out, n1, Mx);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *tfhe_last_error(void) { return g_err.c_str(); }
+
+int tfhe_device_count(int *count)
+{
+    if (!count) return fail(TFHE_E_INVALID, "null count");
+    HIP_TRY(hipGetDeviceCount(count));
+    return TFHE_OK;
+}
+
+int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
+{
+    if (!P || !out) return fail(TFHE_E_INVALID, "null argument");
+    int shape = 0;
+    if (P->N == 1024 && P->Nbit == 10 && P->L == 3 && P->Bgbit == 6) shape = 1;
+    if (!shape)
+        return fail(TFHE_E_INVALID, "unsupported parameter shape N=%d L=%d Bgbit=%d (supported: N=1024,L=3,Bgbit=6)",
+                    P->N, P->L, P->Bgbit);
+    if (P->n < 1 || P->n >= kMaxLweDim) return fail(TFHE_E_INVALID, "LWE dimension %d out of range", P->n);
+    if (P->basebit < 1 || P->t < 1 || P->basebit * P->t > 31 || (size_t)P->N * P->t > 9216)
+        return fail(TFHE_E_INVALID, "unsupported key-switch shape basebit=%d t=%d", P->basebit, P->t);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(TFHE_E_INVALID, "device %d not present (%d visible)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    tfhe_ctx *c = new tfhe_ctx;
+    c->P = *P; c->device = device_id; c->shape = shape;
+    c->n1p = (P->n + 1 + 3) & ~3;
+    for (int i = 0; i < P->L; i++) c->offset += (1u << (P->Bgbit - 1)) * (1u << (32 - (i + 1) * P->Bgbit));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &pair : c->ev)
+        for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
+    std::vector<cd> tw = make_twiddles_1024();
+    int rc;
+    if ((rc = c->tw.reserve(tw.size() * sizeof(cd)))) { delete c; return rc; }
+    HIP_TRY(hipMemcpy(c->tw.p, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
+    std::vector<uint32_t> tv(2 * (size_t)P->N, 0u);              // cloudkey.go:74-85
+    for (int j = 0; j < P->N; j++) tv[P->N + j] = 0x20000000u;
+    if ((rc = c->gate_tv.reserve(tv.size() * sizeof(uint32_t)))) { delete c; return rc; }
+    HIP_TRY(hipMemcpy(c->gate_tv.p, tv.data(), tv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    *out = c;
+    return TFHE_OK;
+}
+
+int tfhe_ctx_destroy(tfhe_ctx *c)
+{
+    if (!c) return TFHE_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->bsk, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
+                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3})
+        b->release();
+    for (auto &pair : c->ev)
+        for (auto &e : pair) if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TFHE_OK;
+}
+
+int tfhe_ctx_params(const tfhe_ctx *c, tfhe_params *out)
+{
+    if (!c || !out) return fail(TFHE_E_INVALID, "null argument");
+    *out = c->P;
+    return TFHE_OK;
+}
+
+int tfhe_ctx_sync(tfhe_ctx *c)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!bsk) return fail(TFHE_E_INVALID, "null key");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t elems = bsk_elems(c->P), bytes = elems * sizeof(cd);
+    DevBuf raw;
+    if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bytes))) { raw.release(); return rc; }
+    HIP_TRY(hipMemcpyAsync(raw.p, bsk, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bsk_from_fourier, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                       raw.as<double>(), c->bsk.as<cd>(), c->P.n, c->P.L);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    raw.release();
+    c->have_bsk = true;
+    return TFHE_OK;
+}
+
+int tfhe_load_bsk_torus(tfhe_ctx *c, const uint32_t *bsk)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!bsk) return fail(TFHE_E_INVALID, "null key");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t polys = (size_t)c->P.n * 2 * c->P.L * 2, bytes = polys * c->P.N * sizeof(uint32_t);
+    DevBuf raw;
+    if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bsk_elems(c->P) * sizeof(cd)))) { raw.release(); return rc; }
+    HIP_TRY(hipMemcpyAsync(raw.p, bsk, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_bsk_from_torus, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
+                       c->bsk.as<cd>(), c->tw.as<cd>(), c->P.L);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    raw.release();
+    c->have_bsk = true;
+    return TFHE_OK;
+}
+
+int tfhe_load_ksk(tfhe_ctx *c, const uint32_t *ksk)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!ksk) return fail(TFHE_E_INVALID, "null key");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const int n1 = c->P.n + 1, base = 1 << c->P.basebit;
+    const size_t ref_bytes = ksk_rows_ref(c->P) * n1 * sizeof(uint32_t);
+    const size_t rows_p = ksk_rows_packed(c->P), total = rows_p * c->n1p;
+    DevBuf raw;
+    if ((rc = raw.reserve(ref_bytes)) || (rc = c->ksk.reserve(total * sizeof(uint32_t)))) { raw.release(); return rc; }
+    HIP_TRY(hipMemcpyAsync(raw.p, ksk, ref_bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_ksk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, raw.as<uint32_t>(),
+                       c->ksk.as<uint32_t>(), n1, c->n1p, base, rows_p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    raw.release();
+    c->have_ksk = true;
+    return TFHE_OK;
+}
+
+int tfhe_blind_rotate_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,
+                                uint32_t *d_out, int B, int nsteps, void *stream)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    return launch_blind_rotate(c, d_in, nullptr, nullptr, -1, d_tv, tv_per_item, d_out, B, nsteps, pick(c, stream));
+}
+
+int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *c, const uint32_t *d_in, uint32_t *d_out, int B, void *stream)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    return launch_keyswitch(c, d_in, d_out, B, pick(c, stream));
+}
+
+int tfhe_bootstrap_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,
+                             uint32_t *d_out, int B, void *stream)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
+    if (B == 0) return TFHE_OK;
+    if ((rc = c->s_trlwe.reserve((size_t)B * 2 * c->P.N * sizeof(uint32_t)))) return rc;
+    hipStream_t st = pick(c, stream);
+    if ((rc = launch_blind_rotate(c, d_in, nullptr, nullptr, -1, d_tv, tv_per_item, c->s_trlwe.as<uint32_t>(), B, -1, st))) return rc;
+    return launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), d_out, B, st);
+}
+
+int tfhe_gate_batch_dev(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a, const uint32_t *d_b,
+                        const uint32_t *d_c, uint32_t *d_out, int B, void *stream)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!d_a || !d_b || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
+    if (B == 0) return TFHE_OK;
+    hipStream_t st = pick(c, stream);
+    std::vector<uint8_t> h_ops;
+    if (d_ops) {            // the MUX split needs the op codes on the host
+        h_ops.resize(B);
+        HIP_TRY(hipMemcpyAsync(h_ops.data(), d_ops, B, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return gate_batch_device(c, d_ops, d_ops ? h_ops.data() : nullptr, op_uniform, d_a, d_b, d_c, d_out, B, st);
+}
+
+// ---- host-pointer variants: stage, run, copy back, synchronise -----------------------
+
+int tfhe_blind_rotate_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out,
+                            int B, int nsteps)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
+    const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
+    if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_trlwe.reserve(trl)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
+    if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_blind_rotate(c, c->s_in0.as<uint32_t>(), nullptr, nullptr, -1, tv ? c->s_tv.as<uint32_t>() : nullptr,
+                                  tv_per_item, c->s_trlwe.as<uint32_t>(), B, nsteps, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_trlwe.p, trl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_extract_keyswitch_batch(tfhe_ctx *c, const uint32_t *in, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t outb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
+    if ((rc = c->s_out.reserve(outb)) || (rc = c->s_trlwe.reserve(trl))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), c->s_out.as<uint32_t>(), B, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, outb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_bootstrap_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
+    const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
+    if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_out.reserve(inb)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
+    if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = tfhe_bootstrap_batch_dev(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
+                                       c->s_out.as<uint32_t>(), B, nullptr))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b,
+                    const uint32_t *cc, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!a || !b || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t rows = (size_t)B * (c->P.n + 1) * 4;
+    if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_in1.reserve(rows)) || (rc = c->s_out.reserve(rows))) return rc;
+    if (cc && (rc = c->s_in2.reserve(rows))) return rc;
+    if (ops && (rc = c->s_ops.reserve(B))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, a, rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_in1.p, b, rows, hipMemcpyHostToDevice, c->stream));
+    if (cc) HIP_TRY(hipMemcpyAsync(c->s_in2.p, cc, rows, hipMemcpyHostToDevice, c->stream));
+    if (ops) HIP_TRY(hipMemcpyAsync(c->s_ops.p, ops, B, hipMemcpyHostToDevice, c->stream));
+    if ((rc = gate_batch_device(c, ops ? c->s_ops.as<uint8_t>() : nullptr, ops, op_uniform, c->s_in0.as<uint32_t>(),
+                                c->s_in1.as<uint32_t>(), cc ? c->s_in2.as<uint32_t>() : nullptr,
+                                c->s_out.as<uint32_t>(), B, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (!c->have_bsk) return fail(TFHE_E_NOKEY, "bootstrapping key not loaded");
+    if (key_index < 0 || key_index >= c->P.n) return fail(TFHE_E_INVALID, "key index %d out of range", key_index);
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t trl = (size_t)B * 2 * c->P.N * 4;
+    if ((rc = c->s_trlwe.reserve(trl)) || (rc = c->s_t0.reserve(trl))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, c->stream, c->bsk.as<cd>(), c->tw.as<cd>(),
+                       key_index, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->offset);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->s_t0.p, trl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_to_fourier_batch(tfhe_ctx *c, const uint32_t *polys, double *spectra, int P)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (P < 0 || (P > 0 && (!polys || !spectra))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (P == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
+    if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_t0.p, polys, pb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_to_fourier, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(), c->s_t1.as<double>(),
+                       c->tw.as<cd>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(spectra, c->s_t1.p, sb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_to_poly_batch(tfhe_ctx *c, const double *spectra, uint32_t *polys, int P)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (P < 0 || (P > 0 && (!polys || !spectra))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (P == 0) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
+    if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_t1.p, spectra, sb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_to_poly, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
+                       c->tw.as<cd>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(polys, c->s_t0.p, pb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_last_kernel_ms(tfhe_ctx *c, int which, float *ms)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!ms || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    if (!c->ev_valid[which]) return fail(TFHE_E_INVALID, "no launch recorded");
+    HIP_TRY(hipEventSynchronize(c->ev[which][1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
+    return TFHE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,148 @@
+/*
+ * tfhe_hip.h -- C ABI of the MI355X (gfx950) gate-bootstrapping engine.
+ *
+ * This is the drop-in boundary for go-tfhe's hot path.  The reference is pure Go
+ * with no FFI layer; each entry point below replaces one of its in-process seams
+ * (file:line relative to the go-tfhe tree) and is what a cgo shim binds
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative
+ *     TFHE_E_* code and never throws; tfhe_last_error() gives the message.  The
+ *     reference panics on every error on this path; the cgo shim turns rc != 0 into
+ *     panic() to keep that behaviour.
+ *   - a context belongs to ONE GPU and is single-submitter, like evaluator.Evaluator
+ *     (evaluator.go:14-24: "not goroutine-safe"); use one context per GPU/goroutine.
+ *   - keys are copied at load time and are immutable afterwards.
+ *   - outputs are caller-owned (the *Assign style of the reference).
+ *   - "_dev" variants take DEVICE pointers and a hipStream_t (as void*; NULL = the
+ *     context's own stream) and only enqueue work; the others take HOST pointers and
+ *     return after the result is in the output buffer.
+ *   - all ciphertext words are uint32 torus values (params.Torus, params.go:27);
+ *     an LWE sample is n+1 words with the body LAST (tlwe.go:11-33); a TRLWE sample is
+ *     [2][N] words, A then B (trlwe.go:13-16).
+ */
+#ifndef TFHE_HIP_H
+#define TFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFHE_OK            0
+#define TFHE_E_INVALID    -1   /* bad argument / unsupported parameter set          */
+#define TFHE_E_NOKEY      -2   /* bootstrapping or key-switching key not loaded    */
+#define TFHE_E_HIP        -3   /* HIP runtime error (message has the hipError_t)   */
+#define TFHE_E_NOMEM      -4
+
+/* The fields of params.TRGSWLv1Params / TLWELv0Params the path reads
+ * (params.go:60-78).  Replaces the process-global params.CurrentSecurityLevel
+ * (params.go:47): parameters are explicit per context. */
+typedef struct {
+    int32_t n;        /* TLWELv0.N                       */
+    int32_t N;        /* TRGSWLv1.N  (1024 or 2048)      */
+    int32_t Nbit;     /* TRGSWLv1.NBIT                   */
+    int32_t L;        /* TRGSWLv1.L                      */
+    int32_t Bgbit;    /* TRGSWLv1.BGBIT                  */
+    int32_t basebit;  /* TRGSWLv1.BASEBIT                */
+    int32_t t;        /* TRGSWLv1.IKS_T                  */
+} tfhe_params;
+
+/* Gate op codes for tfhe_gate_batch*: gates.go:26-114 / gates_helper.go:10-63. */
+enum {
+    TFHE_OP_NAND = 0, TFHE_OP_AND = 1, TFHE_OP_OR = 2, TFHE_OP_XOR = 3, TFHE_OP_XNOR = 4,
+    TFHE_OP_NOR = 5, TFHE_OP_ANDNY = 6, TFHE_OP_ANDYN = 7, TFHE_OP_ORNY = 8, TFHE_OP_ORYN = 9,
+    TFHE_OP_MUX = 10
+};
+
+typedef struct tfhe_ctx tfhe_ctx;
+
+const char *tfhe_last_error(void);
+/* Number of visible GPUs (hipGetDeviceCount). */
+int tfhe_device_count(int *count);
+
+/* evaluator.NewEvaluator (evaluator.go:27-35) + the CloudKey fields that are pure
+ * functions of the parameters (cloudkey.go:60-85: decomposition offset, gate test
+ * vector).  Supported parameter shapes: N=1024 with L=3,Bgbit=6 (the 80/110/128-bit
+ * sets) and N=2048 with L=1,Bgbit=22 (Uint5); anything else returns TFHE_E_INVALID. */
+int tfhe_ctx_create(const tfhe_params *params, int device_id, tfhe_ctx **out);
+int tfhe_ctx_destroy(tfhe_ctx *ctx);
+int tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
+int tfhe_ctx_sync(tfhe_ctx *ctx);
+
+/* CloudKey.BootstrappingKey (cloudkey.go:16-21, []*trgsw.TRGSWLv1FFT, trgsw.go:60-68),
+ * flattened by the shim to [n][2L][2][N] float64: row r < L multiplies the digits of A,
+ * row L+r the digits of B (trgsw.go:51-54); part 0 = A, 1 = B; each [N] is one
+ * poly.FourierPoly in the reference's own layout and slot order (poly.go:54-62,
+ * fourier_transform.go:64-85,178-247).  The engine permutes it into its wave-native
+ * layout on the GPU. */
+int tfhe_load_bsk_fourier(tfhe_ctx *ctx, const double *bsk);
+/* The same key in the coefficient domain, [n][2L][2][N] uint32 (trgsw.TRGSWLv1,
+ * trgsw.go:14-30); the engine runs its own forward FFT (trgsw.go:71-82). */
+int tfhe_load_bsk_torus(tfhe_ctx *ctx, const uint32_t *bsk);
+/* CloudKey.KeySwitchingKey (cloudkey.go:88-120): [N*t*base][n+1] uint32, flat index
+ * base*t*i + base*j + k (keyswitch.go:29). */
+int tfhe_load_ksk(tfhe_ctx *ctx, const uint32_t *ksk);
+
+/* Evaluator.BootstrapAssign / BootstrapLUTAssign over a batch (evaluator.go:139-148,
+ * programmable_bootstrap.go:93-115; batch fan-out trgsw.go:234-252).
+ *   in      [B][n+1]
+ *   testvec [2][N] shared (testvec_per_item = 0) or [B][2][N] (= 1);
+ *           NULL = the gate test vector (cloudkey.go:74-85)
+ *   out     [B][n+1] */
+int tfhe_bootstrap_batch(tfhe_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                         int testvec_per_item, uint32_t *out, int B);
+int tfhe_bootstrap_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in, const uint32_t *d_testvec,
+                             int testvec_per_item, uint32_t *d_out, int B, void *stream);
+
+/* Evaluator.BlindRotateAssign / trgsw.BatchBlindRotate (evaluator.go:110-135,
+ * trgsw.go:234-252): out_trlwe [B][2][N].  nsteps < 0 means all n CMUX steps; a
+ * smaller value stops the chain early (test seam for CMuxAssign, evaluator.go:85-106). */
+int tfhe_blind_rotate_batch(tfhe_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                            int testvec_per_item, uint32_t *out_trlwe, int B, int nsteps);
+int tfhe_blind_rotate_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in, const uint32_t *d_testvec,
+                                int testvec_per_item, uint32_t *d_out_trlwe, int B, int nsteps,
+                                void *stream);
+
+/* Evaluator.ExternalProductAssign (evaluator.go:50-81) of in[b] with bootstrapping-key
+ * element bsk[key_index]: in/out [B][2][N]. */
+int tfhe_external_product_batch(tfhe_ctx *ctx, int key_index, const uint32_t *in_trlwe,
+                                uint32_t *out_trlwe, int B);
+
+/* trlwe.SampleExtractIndexAssign(.,0,.) + trgsw.IdentityKeySwitchingAssign
+ * (trlwe_ops.go:10-21, keyswitch.go:10-37): in [B][2][N] -> out [B][n+1]. */
+int tfhe_extract_keyswitch_batch(tfhe_ctx *ctx, const uint32_t *in_trlwe, uint32_t *out, int B);
+int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, uint32_t *d_out,
+                                     int B, void *stream);
+
+/* gates.NAND ... gates.ORYN, gates.MUX and gates.Batch* (gates.go:26-114,156-312):
+ * the linear preparation (gates_helper.go:10-63) is fused into the bootstrap kernel.
+ *   ops: per-item op codes [B], or NULL with op_uniform = one TFHE_OP_* for all items
+ *   a, b: [B][n+1]; c: [B][n+1], required iff any op is TFHE_OP_MUX (3 bootstraps,
+ *   gates.go:107-114), may be NULL otherwise.
+ * Batch XNOR follows the tested scalar gates.XNOR (+1/4, gates.go:52-58), not
+ * BatchXNOR's -1/4 (gates.go:293), which computes XOR. */
+int tfhe_gate_batch(tfhe_ctx *ctx, const uint8_t *ops, int op_uniform, const uint32_t *a,
+                    const uint32_t *b, const uint32_t *c, uint32_t *out, int B);
+int tfhe_gate_batch_dev(tfhe_ctx *ctx, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a,
+                        const uint32_t *d_b, const uint32_t *d_c, uint32_t *d_out, int B,
+                        void *stream);
+
+/* poly.Evaluator.ToFourierPolyAssign / ToPolyAssignUnsafe over a batch of polynomials
+ * (fourier_transform.go:18-21,40-44), spectra in the reference FourierPoly layout:
+ * polys [P][N] uint32 <-> spectra [P][N] float64.  Test seams for the FFT. */
+int tfhe_to_fourier_batch(tfhe_ctx *ctx, const uint32_t *polys, double *spectra, int P);
+int tfhe_to_poly_batch(tfhe_ctx *ctx, const double *spectra, uint32_t *polys, int P);
+
+/* Elapsed GPU time (ms) of the most recent blind-rotate kernel launch on this context,
+ * measured with HIP events on the stream it ran on; blocks until it has finished.
+ * which: 0 = blind rotate, 1 = sample-extract + key switch. */
+int tfhe_last_kernel_ms(tfhe_ctx *ctx, int which, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,31 @@
+"""Quick on-box sanity + timing (not a pytest file): run as `python tests/gpu_first_light.py`."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import __graft_entry__ as g
+g.build()
+pkg = g.load_package()
+from oracle_lib import Oracle
+o = Oracle()
+p = o.params("128")
+rng = o.rng(5)
+t = time.time()
+s0, s1 = o.keygen_secret(p, rng)
+_, bsk = o.keygen_bsk(p, rng, s0, s1, torus=False)
+ksk = o.keygen_ksk(p, rng, s0, s1)
+print("keygen s", time.time() - t, flush=True)
+ck = pkg.CloudKey(pkg.params.Security128Bit, bsk_fourier=bsk, ksk=ksk)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+rs = np.random.RandomState(0)
+A = rs.randint(0, 2, B); Bb = rs.randint(0, 2, B)
+a = o.encrypt_bools(p, rng, A, s0); b = o.encrypt_bools(p, rng, Bb, s0)
+for it in range(3):
+    t = time.time()
+    out = ck.ctx.gate_batch("NAND", a, b)
+    dt = time.time() - t
+    print(f"iter {it}: {dt*1e3:.1f} ms wall, BR kernel {ck.ctx.last_kernel_ms(0):.2f} ms, KS kernel {ck.ctx.last_kernel_ms(1):.2f} ms, {B/dt:.0f} gates/s", flush=True)
+dec = o.decrypt_bools(p, s0, out)
+print("correct:", int((dec == ~(A.astype(bool) & Bb.astype(bool))).sum()), "/", B)
+want, _ = o.gate_batch(p, bsk, ksk, "NAND", a[:4], b[:4])
+print("bit-exact first 4:", np.array_equal(out[:4], want))

@@ -1,0 +1,184 @@
+"""GPU parity for the hot path: external product, CMUX chain, key switch, bootstrap, gates.
+Integer torus outputs are compared BIT-EXACT with the oracle (and the exact-integer oracle)."""
+import numpy as np
+import pytest
+
+from conftest import rand_u32
+
+pytestmark = pytest.mark.gpu
+
+ALL_OPS = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
+TRUTH = {
+    "NAND": lambda a, b: not (a and b), "AND": lambda a, b: a and b, "OR": lambda a, b: a or b,
+    "XOR": lambda a, b: a != b, "XNOR": lambda a, b: a == b, "NOR": lambda a, b: not (a or b),
+    "ANDNY": lambda a, b: (not a) and b, "ANDYN": lambda a, b: a and (not b),
+    "ORNY": lambda a, b: (not a) or b, "ORYN": lambda a, b: a or (not b),
+}
+
+
+def test_external_product_bit_exact(oracle, keys_small, ck_small):
+    k = keys_small
+    rs = np.random.RandomState(10)
+    trl = rand_u32(rs, (6, 2, 1024))
+    trl[0] = 0                                  # zero input -> zero digits -> zero output
+    for idx in (0, 7, k.p.n - 1):
+        got = ck_small.ctx.external_product_batch(idx, trl)
+        for b in range(trl.shape[0]):
+            assert np.array_equal(got[b], oracle.external_product(k.p, k.bsk[idx], trl[b])), (idx, b)
+            assert np.array_equal(got[b], oracle.external_product_exact(k.p, k.bsk_torus[idx], trl[b])), (idx, b)
+    assert not ck_small.ctx.external_product_batch(0, trl)[0].any()
+
+
+def test_bsk_torus_upload_equals_fourier_upload(pkg, oracle, keys_small):
+    from conftest import gpu_params
+    k = keys_small
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_torus=k.bsk_torus, ksk=k.ksk)
+    rs = np.random.RandomState(11)
+    trl = rand_u32(rs, (3, 2, 1024))
+    got = ck.ctx.external_product_batch(5, trl)
+    for b in range(3):
+        assert np.array_equal(got[b], oracle.external_product_exact(k.p, k.bsk_torus[5], trl[b]))
+    ck.close()
+
+
+@pytest.mark.parametrize("nsteps", [0, 1, 2, 9, -1])
+def test_blind_rotate_prefix_bit_exact(oracle, keys_small, ck_small, nsteps):
+    k = keys_small
+    rs = np.random.RandomState(12)
+    cts = rand_u32(rs, (5, k.p.n + 1))
+    cts[0] = 0                                   # b = 0 -> btilde = 2N (wraps to 0), all atilde = 0
+    cts[1] = 0xFFFFFFFF                          # extreme mod-switch inputs
+    got = ck_small.ctx.blind_rotate_batch(cts, None, nsteps)
+    for b in range(cts.shape[0]):
+        want = oracle.blind_rotate(k.p, k.bsk, cts[b], k.tv, nsteps)
+        assert np.array_equal(got[b], want), (nsteps, b)
+
+
+def test_blind_rotate_per_item_testvec(oracle, keys_small, ck_small):
+    k = keys_small
+    rs = np.random.RandomState(13)
+    cts = rand_u32(rs, (3, k.p.n + 1))
+    tvs = rand_u32(rs, (3, 2, 1024))
+    got = ck_small.ctx.blind_rotate_batch(cts, tvs)
+    for b in range(3):
+        assert np.array_equal(got[b], oracle.blind_rotate(k.p, k.bsk, cts[b], tvs[b]))
+    got1 = ck_small.ctx.blind_rotate_batch(cts, tvs[0])
+    for b in range(3):
+        assert np.array_equal(got1[b], oracle.blind_rotate(k.p, k.bsk, cts[b], tvs[0]))
+
+
+def test_blind_rotate_vs_exact_integer_oracle(oracle, keys_small, ck_small):
+    k = keys_small
+    rs = np.random.RandomState(14)
+    cts = rand_u32(rs, (2, k.p.n + 1))
+    got = ck_small.ctx.blind_rotate_batch(cts)
+    for b in range(2):
+        assert np.array_equal(got[b], oracle.blind_rotate_exact(k.p, k.bsk_torus, cts[b], k.tv))
+
+
+@pytest.mark.parametrize("which", ["small", "80", "128"])
+def test_extract_keyswitch_bit_exact(oracle, request, which):
+    k = request.getfixturevalue({"small": "keys_small", "80": "keys80", "128": "keys128"}[which])
+    ck = request.getfixturevalue({"small": "ck_small", "80": "ck80", "128": "ck128"}[which])
+    rs = np.random.RandomState(15)
+    trl = rand_u32(rs, (5, 2, 1024))
+    trl[0] = 0                                   # all digits: a_i = ~0 except a_0 = 0
+    trl[1] = 0xFFFFFFFF
+    got = ck.ctx.extract_keyswitch_batch(trl)
+    for b in range(trl.shape[0]):
+        want = oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[b]))
+        assert np.array_equal(got[b], want), b
+
+
+def test_bootstrap_80bit_bit_exact_and_decrypts(oracle, keys80, ck80):
+    k = keys80
+    bits = [0, 1, 1]
+    cts = k.enc(bits)
+    got = ck80.ctx.bootstrap_batch(cts)
+    for b in range(len(bits)):
+        assert np.array_equal(got[b], oracle.bootstrap(k.p, k.bsk, k.ksk, cts[b], k.tv))
+    assert list(k.dec(got)) == [bool(x) for x in bits]
+
+
+@pytest.mark.parametrize("op", ALL_OPS)
+def test_gate_truth_tables_128bit(oracle, keys128, ck128, op):
+    # mirrors gates/gates_test.go:23-366 (default = 128-bit parameters)
+    k = keys128
+    A, B = [0, 0, 1, 1], [0, 1, 0, 1]
+    a, b = k.enc(A), k.enc(B)
+    out = ck128.ctx.gate_batch(op, a, b)
+    assert list(k.dec(out)) == [bool(TRUTH[op](bool(x), bool(y))) for x, y in zip(A, B)]
+    # bit-exact vs the oracle's prepare + bootstrap for one of the four
+    want = oracle.gate(k.p, k.bsk, k.ksk, op, a[2], b[2])
+    assert np.array_equal(out[2], want)
+
+
+def test_mux_truth_table_128bit(oracle, keys128, ck128, pkg):
+    k = keys128
+    A = [0, 0, 0, 0, 1, 1, 1, 1]; B = [0, 0, 1, 1, 0, 0, 1, 1]; C = [0, 1, 0, 1, 0, 1, 0, 1]
+    a, b, c = k.enc(A), k.enc(B), k.enc(C)
+    out = ck128.ctx.gate_batch("MUX", a, b, c)
+    assert list(k.dec(out)) == [bool(y if x else z) for x, y, z in zip(A, B, C)]
+    assert np.array_equal(out[5], oracle.gate(k.p, k.bsk, k.ksk, "MUX", a[5], b[5], c[5]))
+    # scalar API (gates.MUX, gates.go:107-114)
+    assert np.array_equal(pkg.gates.MUX(a[5], b[5], c[5], ck128), out[5])
+
+
+def test_mixed_gate_stream_small(oracle, keys_small, ck_small, pkg):
+    # per-item op codes incl. MUX; bit-exact against the oracle on random (noise-free-ish) samples
+    k = keys_small
+    rs = np.random.RandomState(16)
+    names = ["AND", "OR", "XOR", "MUX", "NAND", "MUX", "ORYN", "XNOR", "MUX"]
+    B = len(names)
+    a, b, c = (rand_u32(rs, (B, k.p.n + 1)) for _ in range(3))
+    got = pkg.gates.gate_stream(names, a, b, ck_small, c)
+    want, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, [pkg.OPS[x] for x in names], a, b, c)
+    assert np.array_equal(got, want)
+
+
+def test_batch_gates_api(oracle, keys_small, ck_small, pkg):
+    # gates.Batch* (gates.go:156-312); BatchXNOR follows scalar XNOR
+    k = keys_small
+    rs = np.random.RandomState(17)
+    pairs = [(rand_u32(rs, k.p.n + 1), rand_u32(rs, k.p.n + 1)) for _ in range(7)]
+    for name in ["NAND", "AND", "OR", "XOR", "NOR", "XNOR"]:
+        got = getattr(pkg.gates, "Batch" + name)(pairs, ck_small)
+        for (x, y), g in zip(pairs, got):
+            assert np.array_equal(g, oracle.gate(k.p, k.bsk, k.ksk, name, x, y)), name
+    one = pkg.gates.NAND(pairs[0][0], pairs[0][1], ck_small)
+    assert np.array_equal(one, oracle.gate(k.p, k.bsk, k.ksk, "NAND", *pairs[0]))
+
+
+def test_full_size_batch_1024_nand_128bit(oracle, keys128, ck128):
+    # BASELINE config 2 at full size: all 1024 decrypt correctly; a sample is bit-exact
+    k = keys128
+    rs = np.random.RandomState(18)
+    A = rs.randint(0, 2, 1024); B = rs.randint(0, 2, 1024)
+    a, b = k.enc(A), k.enc(B)
+    out = ck128.ctx.gate_batch("NAND", a, b)
+    assert np.array_equal(k.dec(out), ~(A.astype(bool) & B.astype(bool)))
+    idx = [0, 511, 1023]
+    want, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, "NAND", a[idx], b[idx])
+    assert np.array_equal(out[idx], want)
+    # size-independent property: outputs are deterministic (idempotent launch)
+    assert np.array_equal(ck128.ctx.gate_batch("NAND", a, b), out)
+
+
+def test_edge_cases_and_errors(pkg, keys_small, ck_small):
+    from conftest import gpu_params
+    k = keys_small
+    n1 = k.p.n + 1
+    empty = np.empty((0, n1), np.uint32)
+    assert ck_small.ctx.gate_batch("NAND", empty, empty).shape == (0, n1)
+    assert ck_small.ctx.bootstrap_batch(empty).shape == (0, n1)
+    with pytest.raises(pkg.TfheError):                      # unsupported shape
+        pkg.Context(pkg.Params(n=10, N=512, Nbit=9, L=3, Bgbit=6, basebit=2, t=7))
+    bare = pkg.Context(gpu_params(pkg, k.p))
+    with pytest.raises(pkg.TfheError) as e:                 # no key loaded
+        bare.bootstrap_batch(np.zeros((1, n1), np.uint32))
+    assert e.value.code == -2
+    bare.close()
+    with pytest.raises(pkg.TfheError):                      # MUX without third operand
+        ck_small.ctx.gate_batch("MUX", np.zeros((1, n1), np.uint32), np.zeros((1, n1), np.uint32))
+    with pytest.raises(pkg.TfheError):                      # bad op code
+        ck_small.ctx.gate_batch(np.array([77], np.uint8), np.zeros((1, n1), np.uint32), np.zeros((1, n1), np.uint32))
