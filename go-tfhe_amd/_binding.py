@@ -68,6 +68,8 @@ def load_library():
         "tfhe_to_fourier_batch": [vp, u32p, f64p, C.c_int],
         "tfhe_to_poly_batch": [vp, f64p, u32p, C.c_int],
         "tfhe_last_kernel_ms": [vp, C.c_int, C.POINTER(C.c_float)],
+        "tfhe_timing_enable": [vp, C.c_int],
+        "tfhe_timing_read": [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -268,6 +270,15 @@ class Context:
 
     def sync(self):
         self._check(self._lib.tfhe_ctx_sync(self._h))
+
+    def timing_enable(self, on=True):
+        self._check(self._lib.tfhe_timing_enable(self._h, int(bool(on))))
+
+    def timing_read(self, which=0):
+        """(launches, total_ms) of kernel `which` since the last read (blocks until finished)."""
+        cnt, ms = C.c_int(), C.c_float()
+        self._check(self._lib.tfhe_timing_read(self._h, int(which), C.byref(cnt), C.byref(ms)))
+        return cnt.value, ms.value
 
     def last_kernel_ms(self, which=0):
         ms = C.c_float()

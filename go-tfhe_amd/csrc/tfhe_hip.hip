@@ -73,6 +73,10 @@ struct tfhe_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool ev_valid[2] = {false, false};
+    // cumulative timing (tfhe_timing_*): one event pair per launch while enabled
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev[2];
+    std::vector<hipEvent_t> ev_pool;
     DevBuf bsk, ksk, tw, gate_tv;
     bool have_bsk = false, have_ksk = false;
     // staging (grow-only)
@@ -112,6 +116,24 @@ std::vector<cd> make_twiddles_1024()
     return t;
 }
 
+// Event pair bracketing one launch of kernel `which` on stream st.
+int timing_begin(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t *stop)
+{
+    hipEvent_t a, b;
+    if (c->timing) {
+        for (hipEvent_t *e : {&a, &b}) {
+            if (!c->ev_pool.empty()) { *e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else HIP_TRY(hipEventCreate(e));
+        }
+        c->tev[which].emplace_back(a, b);
+    } else {
+        a = c->ev[which][0]; b = c->ev[which][1];
+    }
+    HIP_TRY(hipEventRecord(a, st));
+    *stop = b;
+    return TFHE_OK;
+}
+
 int check_ctx(tfhe_ctx *c)
 {
     if (!c) return fail(TFHE_E_INVALID, "null context");
@@ -135,14 +157,16 @@ int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in
     a.n = c->P.n; a.Nbit = c->P.Nbit;
     a.nsteps = (nsteps < 0 || nsteps > c->P.n) ? c->P.n : nsteps;
     a.offset = c->offset;
-    HIP_TRY(hipEventRecord(c->ev[0][0], st));
+    hipEvent_t stop;
+    int trc = timing_begin(c, 0, st, &stop);
+    if (trc) return trc;
     if (c->shape == 1)
         hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a);
     else
         return fail(TFHE_E_INVALID, "parameter shape %d has no blind-rotate kernel", c->shape);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[0][1], st));
-    c->ev_valid[0] = true;
+    HIP_TRY(hipEventRecord(stop, st));
+    c->ev_valid[0] = !c->timing;
     return TFHE_OK;
 }
 
@@ -154,7 +178,9 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     a.trlwe = d_trlwe; a.ksk = c->ksk.as<uint32_t>(); a.out = d_out;
     a.n = c->P.n; a.N = c->P.N; a.t = c->P.t; a.basebit = c->P.basebit; a.n1p = c->n1p;
     const int ch = (c->n1p + 255) / 256;
-    HIP_TRY(hipEventRecord(c->ev[1][0], st));
+    hipEvent_t stop;
+    int trc = timing_begin(c, 1, st, &stop);
+    if (trc) return trc;
     switch (ch) {
     case 1: hipLaunchKernelGGL((k_extract_keyswitch<1>), dim3(B), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL((k_extract_keyswitch<2>), dim3(B), dim3(256), 0, st, a); break;
@@ -164,8 +190,8 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     default: return fail(TFHE_E_INVALID, "LWE dimension %d too large for the key-switch kernel", c->P.n);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[1][1], st));
-    c->ev_valid[1] = true;
+    HIP_TRY(hipEventRecord(stop, st));
+    c->ev_valid[1] = !c->timing;
     return TFHE_OK;
 }
 
@@ -285,6 +311,9 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
         b->release();
     for (auto &pair : c->ev)
         for (auto &e : pair) if (e) (void)hipEventDestroy(e);
+    for (auto &v : c->tev)
+        for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TFHE_OK;
@@ -559,6 +588,34 @@ int tfhe_last_kernel_ms(tfhe_ctx *c, int which, float *ms)
     if (!c->ev_valid[which]) return fail(TFHE_E_INVALID, "no launch recorded");
     HIP_TRY(hipEventSynchronize(c->ev[which][1]));
     HIP_TRY(hipEventElapsedTime(ms, c->ev[which][0], c->ev[which][1]));
+    return TFHE_OK;
+}
+
+int tfhe_timing_enable(tfhe_ctx *c, int on)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    c->timing = on != 0;
+    return TFHE_OK;
+}
+
+int tfhe_timing_read(tfhe_ctx *c, int which, int *launches, float *total_ms)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!launches || !total_ms || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    float sum = 0.f;
+    for (auto &pr : c->tev[which]) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(pr.second));
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+        c->ev_pool.push_back(pr.first);
+        c->ev_pool.push_back(pr.second);
+    }
+    *launches = (int)c->tev[which].size();
+    *total_ms = sum;
+    c->tev[which].clear();
     return TFHE_OK;
 }
 

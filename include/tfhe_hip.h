@@ -142,6 +142,13 @@ int tfhe_to_poly_batch(tfhe_ctx *ctx, const double *spectra, uint32_t *polys, in
  * which: 0 = blind rotate, 1 = sample-extract + key switch. */
 int tfhe_last_kernel_ms(tfhe_ctx *ctx, int which, float *ms);
 
+/* Cumulative per-kernel timing for benchmarks: while enabled, every launch of the two path
+ * kernels is bracketed by its own HIP event pair on the stream it is launched on.
+ * tfhe_timing_read blocks until those launches have finished, returns their count and summed
+ * duration, and clears the list.  which: 0 = blind rotate, 1 = extract + key switch. */
+int tfhe_timing_enable(tfhe_ctx *ctx, int on);
+int tfhe_timing_read(tfhe_ctx *ctx, int which, int *launches, float *total_ms);
+
 #ifdef __cplusplus
 }
 #endif
