@@ -1,0 +1,74 @@
+"""CPU tier: the multi-GPU batch scatter / compute / gather path with world_size 2 over gloo.
+The per-rank compute is the oracle here (no GPU in this tier); on the GPU box the same
+ShardedGates object is driven by go_tfhe_amd.distributed.gpu_compute (RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    from oracle_lib import Oracle
+    from conftest import KeySet
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = graft.load_package()
+    from go_tfhe_amd.distributed import ShardedGates
+    o = Oracle()
+    ks = KeySet(o, "128", 0x7F4E0003, n_override=8)          # same seed on every rank = replicated key
+    n1 = ks.p.n + 1
+
+    def compute(ops, a, b, c):
+        an, bn = a.numpy().view(np.uint32), b.numpy().view(np.uint32)
+        cn = c.numpy().view(np.uint32) if c is not None else None
+        op = ops if isinstance(ops, str) else ops.numpy()
+        out, _ = o.gate_batch(ks.p, ks.bsk, ks.ksk, op, np.ascontiguousarray(an), np.ascontiguousarray(bn),
+                              None if cn is None else np.ascontiguousarray(cn), nthreads=2)
+        return torch.from_numpy(out.view(np.int32))
+
+    eng = ShardedGates(compute, n1)
+    B = 7                                                      # ragged: shards of 3 and 4
+    rs = np.random.RandomState(21)
+    names = ["AND", "OR", "XOR", "MUX", "NAND", "MUX", "XNOR"]
+    if rank == 0:
+        a, b, c = (rs.randint(0, 2**32, size=(B, n1), dtype=np.uint64).astype(np.uint32) for _ in range(3))
+        ops = np.array([pkg.OPS[x] for x in names], np.uint8)
+        ta, tb, tc = (torch.from_numpy(x.view(np.int32)) for x in (a, b, c))
+        got = eng.gate_batch(torch.from_numpy(ops), ta, tb, tc)
+        want, _ = o.gate_batch(ks.p, ks.bsk, ks.ksk, ops, a, b, c)
+        ok = np.array_equal(got.numpy().view(np.uint32), want)
+        got2 = eng.gate_batch("NAND", ta, tb)                   # uniform op, no third operand
+        want2, _ = o.gate_batch(ks.p, ks.bsk, ks.ksk, "NAND", a, b)
+        ok = ok and np.array_equal(got2.numpy().view(np.uint32), want2)
+        got3 = eng.gate_batch("NAND", ta[:1], tb[:1])           # batch smaller than the world
+        ok = ok and np.array_equal(got3.numpy().view(np.uint32), want2[:1])
+        q.put(ok)
+    else:
+        eng.gate_batch(None, None, None, None)
+        eng.gate_batch(None, None, None, None)
+        eng.gate_batch(None, None, None, None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gates_world2_gloo(built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
