@@ -86,14 +86,101 @@ constexpr int kMaxLweDim = 1088;
 // polynomials of its own half, multiplies them with its L key rows into partial sums for
 // BOTH outputs, hands the partner's partial sum over through LDS, and inverse-transforms
 // its own.  (evaluator.go:50-81; decomposer.go:55-66; fourier_ops.go:167-191)
+// Key slices of one gadget level for one wave: 8 register-slices of the spectrum it keeps and
+// 8 of the spectrum it hands to its partner (64 VGPRs), fetched one level ahead of use so the
+// L2/MALL latency hides under the forward FFT in between.
+struct KeyRegs {
+    cd keep[8], send[8];
+};
+
+__device__ __forceinline__ void load_keys(KeyRegs &K, const cd *__restrict__ key_ipl /* &bsk[i][p][l] */, int p, int lane)
+{
+    const cd *kA = key_ipl + lane;            // part 0: A spectrum of the row
+    const cd *kB = key_ipl + 512 + lane;      // part 1: B spectrum
+    // wave p keeps output p: p = 0 accumulates the A output from part 0, p = 1 the B output
+    const cd *kKeep = p ? kB : kA;
+    const cd *kSend = p ? kA : kB;
+#ifdef ABLATE_KEYLOAD
+    // same addresses every step: stays L1/L2 hot (timing experiment only, wrong results)
+    kKeep = (const cd *)((uintptr_t)kKeep & 0xFFFFFFFFFFFF0000ull) + lane;
+    kSend = kKeep + 512;
+#endif
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        K.keep[k] = kKeep[k * 64];
+        K.send[k] = kSend[k * 64];
+    }
+}
+
+// Source of the polynomial to decompose: either X^at*acc - acc read from this wave's LDS
+// accumulator (blind rotate; re-read per gadget level so the 16 words need not stay in VGPRs
+// across the transforms), or a plain polynomial in global memory (external-product seam).
+struct DiffSource {
+    const uint32_t *accL;   // LDS accumulator of this wave's polynomial, or nullptr
+    int at;                 // rotation amount in [0, 2N)
+    const uint32_t *plain;  // global polynomial when accL == nullptr
+};
+
+__device__ __forceinline__ uint32_t diff_coeff(const DiffSource &S, int j)
+{
+    constexpr int N = 1024;
+    if (!S.accL) return S.plain[j];
+    const int s = (j - S.at) & (2 * N - 1);
+    uint32_t v = S.accL[s & (N - 1)];
+    v ^= 0u - (uint32_t)((s >> 10) & 1);          // "negation" is the bitwise complement
+    return v - S.accL[j];                          // d = X^at*acc - acc (evaluator.go:93-96,122-126)
+}
+
 template <int L, int BGBIT>
-__device__ __forceinline__ void external_product_core(const uint32_t (&d)[16], uint32_t (&e)[16],
+__device__ __forceinline__ void external_product_core(const DiffSource &S, uint32_t (&e)[16],
                                                       const cd *__restrict__ key_ip, /* &bsk[i][p] */
+                                                      const cd *__restrict__ key_next, /* level 0 of the next step or nullptr */
+                                                      KeyRegs &K, /* in: level 0 of this step; out: key_next */
                                                       cd *sc_mine, const cd *sc_other,
                                                       const cd *__restrict__ table, const LaneTwiddles &tw,
                                                       uint32_t offset, int p, int lane)
 {
     cd keep[8], send[8];
+#ifndef TFHE_SERIAL_FFT
+    // All L digit polynomials are transformed as one batch (fft512_forward_batch), then
+    // multiplied into the two accumulators level by level.
+    cd x[L][8];
+    {
+        constexpr uint32_t mask = (1u << BGBIT) - 1u;
+        constexpr int half = 1 << (BGBIT - 1);
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const uint32_t d0 = diff_coeff(S, 64 * a + lane) + offset, d1 = diff_coeff(S, 64 * a + lane + 512) + offset;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int shift = 32 - (l + 1) * BGBIT;
+                x[l][a] = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
+            }
+        }
+    }
+    fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (l == 0) {
+                keep[k] = cmul(x[0][k], K.keep[k]);
+                send[k] = cmul(x[0][k], K.send[k]);
+            } else {
+                cfma(keep[k], x[l][k], K.keep[k]);
+                cfma(send[k], x[l][k], K.send[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            asm volatile("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (l + 1 < L) load_keys(K, key_ip + (size_t)(l + 1) * 2 * 512, p, lane);
+        else if (key_next) load_keys(K, key_next, p, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = send[k] = cd{0.0, 0.0};
 
@@ -105,29 +192,46 @@ __device__ __forceinline__ void external_product_core(const uint32_t (&d)[16], u
         const int shift = 32 - (l + 1) * BGBIT;
 #pragma unroll
         for (int a = 0; a < 8; a++) {
-            int dr = (int)(((d[a] + offset) >> shift) & mask) - half;
-            int di = (int)(((d[a + 8] + offset) >> shift) & mask) - half;
+            const uint32_t d0 = diff_coeff(S, 64 * a + lane), d1 = diff_coeff(S, 64 * a + lane + 512);
+            int dr = (int)(((d0 + offset) >> shift) & mask) - half;
+            int di = (int)(((d1 + offset) >> shift) & mask) - half;
             x[a] = cd{(double)dr, (double)di};
         }
         fft512_forward(x, sc_mine, table, tw, lane);
-        const cd *kA = key_ip + (size_t)(l * 2 + 0) * 512 + lane;
-        const cd *kB = key_ip + (size_t)(l * 2 + 1) * 512 + lane;
-        // wave p keeps output p: for p = 0 "keep" accumulates the A output, for p = 1 the B output
-        const cd *kKeep = p ? kB : kA;
-        const cd *kSend = p ? kA : kB;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            cfma(keep[k], x[k], kKeep[k * 64]);
-            cfma(send[k], x[k], kSend[k * 64]);
+            cfma(keep[k], x[k], K.keep[k]);
+            cfma(send[k], x[k], K.send[k]);
         }
+        // Anchor the accumulators here: pure arithmetic has no ordering against the loads below,
+        // and without this the compiler sinks the MAC past them (keeping the spectrum alive and
+        // spilling the prefetched keys).
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            asm volatile("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
+        }
+        // refill the key registers for the next level (or the next CMUX step) right away
+        __builtin_amdgcn_sched_barrier(0);
+        if (l + 1 < L) load_keys(K, key_ip + (size_t)(l + 1) * 2 * 512, p, lane);
+        else if (key_next) load_keys(K, key_next, p, lane);
+        __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     // hand the partner's partial sum over
 #pragma unroll
     for (int k = 0; k < 8; k++) sc_mine[k * 64 + lane] = send[k];
+#ifndef ABLATE_BARRIER
     __syncthreads();
+#else
+    wave_lds_order();
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
+#ifndef ABLATE_BARRIER
     __syncthreads();
+#else
+    wave_lds_order();
+#endif
     fft512_inverse(keep, sc_mine, table, tw, lane);
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -137,7 +241,7 @@ __device__ __forceinline__ void external_product_core(const uint32_t (&d)[16], u
 }
 
 template <int L, int BGBIT>
-__global__ __launch_bounds__(128) void k_blind_rotate(BlindRotateArgs A)
+__global__ __launch_bounds__(128, 2) void k_blind_rotate(BlindRotateArgs A)
 {
     constexpr int N = 1024;
     __shared__ cd sc[2][kScratchSlots];
@@ -174,7 +278,7 @@ __global__ __launch_bounds__(128) void k_blind_rotate(BlindRotateArgs A)
     __syncthreads();
 
     // ---- acc = X^bt * testvec  (evaluator.go:117-118, buffer_methods.go:133-164)
-    uint32_t acc[16];
+    // The accumulator lives in LDS (accL[p], this wave's polynomial) between steps.
     {
         const int bt = btL & (2 * N - 1);
         const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
@@ -184,45 +288,36 @@ __global__ __launch_bounds__(128) void k_blind_rotate(BlindRotateArgs A)
             const int s = (j - bt) & (2 * N - 1);
             uint32_t v = tv[s & (N - 1)];
             v ^= 0u - (uint32_t)((s >> 10) & 1);      // "negation" is the bitwise complement
-            acc[q] = v;
             accL[p][j] = v;
         }
     }
     wave_lds_order();
 
     const cd *key = A.bsk + (size_t)p * L * 2 * 512;
+    constexpr size_t kStep = (size_t)2 * L * 2 * 512;        // cd elements per CMUX step
     const int nsteps = A.nsteps;
+    KeyRegs K;
+    if (nsteps > 0) load_keys(K, key, p, lane);
     for (int i = 0; i < nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
-        // d = X^at * acc - acc   (evaluator.go:122-126, 93-96)
-        uint32_t d[16], e[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int j = 64 * q + lane;
-            const int s = (j - at) & (2 * N - 1);
-            uint32_t v = accL[p][s & (N - 1)];
-            v ^= 0u - (uint32_t)((s >> 10) & 1);
-            d[q] = v - acc[q];
-        }
-        external_product_core<L, BGBIT>(d, e, key + (size_t)i * 2 * L * 2 * 512, sc[p], sc[p ^ 1], A.tw, tw,
-                                        A.offset, p, lane);
+        uint32_t e[16];
+        const DiffSource S{accL[p], at, nullptr};
+        external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, i + 1 < nsteps ? key + (size_t)(i + 1) * kStep : nullptr,
+                                        K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane);
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            acc[q] += e[q];
-            accL[p][64 * q + lane] = acc[q];
-        }
+        for (int q = 0; q < 16; q++) accL[p][64 * q + lane] += e[q];
         wave_lds_order();
     }
 
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
-    for (int q = 0; q < 16; q++) out[64 * q + lane] = acc[q];
+    for (int q = 0; q < 16; q++) out[64 * q + lane] = accL[p][64 * q + lane];
 }
 
 // ExternalProductAssign of in[b] with bsk[key_index] (test seam).
 template <int L, int BGBIT>
-__global__ __launch_bounds__(128) void k_external_product(const cd *bsk, const cd *twt, int key_index,
+__global__ __launch_bounds__(128, 2) void k_external_product(const cd *bsk, const cd *twt, int key_index,
                                                            const uint32_t *in, uint32_t *out, uint32_t offset)
 {
     constexpr int N = 1024;
@@ -232,11 +327,12 @@ __global__ __launch_bounds__(128) void k_external_product(const cd *bsk, const c
     LaneTwiddles tw;
     load_lane_twiddles(tw, twt, lane);
     const uint32_t *src = in + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
-    uint32_t d[16], e[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) d[q] = src[64 * q + lane];
+    uint32_t e[16];
+    const DiffSource S{nullptr, 0, src};
     const cd *key = bsk + ((size_t)key_index * 2 + p) * L * 2 * 512;
-    external_product_core<L, BGBIT>(d, e, key, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
+    KeyRegs K;
+    load_keys(K, key, p, lane);
+    external_product_core<L, BGBIT>(S, e, key, nullptr, K, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
     uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) dst[64 * q + lane] = e[q];

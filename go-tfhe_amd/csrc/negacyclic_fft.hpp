@@ -61,6 +61,12 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 
 // A wave's DS operations are executed in issue order, so a wave-private LDS exchange only
 // needs the compiler kept from reordering/merging the accesses.
+#ifdef ABLATE_EXCHANGE
+#define TFHE_XCHG(stmt) for (int z_ = 0; z_ < 0; z_++) {}
+#else
+#define TFHE_XCHG(stmt) stmt
+#endif
+
 __device__ __forceinline__ void wave_lds_order()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -83,20 +89,43 @@ constexpr int kTwLevel2 = 16;
 constexpr int kTwLevel3 = 16 + 512;
 constexpr int kTwCount1024 = 16 + 1024;
 
-// Per-lane twiddles kept in VGPRs for the life of a kernel (b, c = 1..7; index 0 unused).
+// Per-lane twiddles kept in VGPRs for the life of a kernel: for each of levels 2 and 3 only
+// w, w^2, w^4 (w = the b = 1 / c = 1 pre-twist); the other four powers are rebuilt with one
+// complex multiply each at every use -- 32 VGPRs traded for 32 fp64 ops per transform, which
+// is what lets the key prefetch stay in registers.
+struct TwPow {
+    cd w1, w2, w4;
+};
 struct LaneTwiddles {
-    cd t2[8];
-    cd t3[8];
+    TwPow l2, l3;
 };
 
 __device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &tw, const cd *__restrict__ table, int lane)
 {
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-        tw.t2[k] = table[kTwLevel2 + k * 64 + lane];
-        tw.t3[k] = table[kTwLevel3 + k * 64 + lane];
+    tw.l2.w1 = table[kTwLevel2 + 1 * 64 + lane];
+    tw.l2.w2 = table[kTwLevel2 + 2 * 64 + lane];
+    tw.l2.w4 = table[kTwLevel2 + 4 * 64 + lane];
+    tw.l3.w1 = table[kTwLevel3 + 1 * 64 + lane];
+    tw.l3.w2 = table[kTwLevel3 + 2 * 64 + lane];
+    tw.l3.w4 = table[kTwLevel3 + 4 * 64 + lane];
+}
+
+// x[c] *= w^c (CONJ: conj(w)^c), c = 1..7, from w, w^2, w^4.  The empty asm makes w1 opaque so
+// the four derived powers are recomputed here instead of being hoisted out of the CMUX loop
+// (which would pin 16 more VGPRs per level).
+template <bool CONJ> __device__ __forceinline__ void twist_pow(cd (&x)[8], const TwPow &t)
+{
+    cd w1 = t.w1;
+    asm volatile("" : "+v"(w1.re), "+v"(w1.im));
+    const cd w3 = cmul(w1, t.w2), w5 = cmul(w1, t.w4), w6 = cmul(t.w2, t.w4);
+    const cd w7 = cmul(w3, t.w4);
+    if (CONJ) {
+        x[1] = cmulc(x[1], w1); x[2] = cmulc(x[2], t.w2); x[3] = cmulc(x[3], w3); x[4] = cmulc(x[4], t.w4);
+        x[5] = cmulc(x[5], w5); x[6] = cmulc(x[6], w6); x[7] = cmulc(x[7], w7);
+    } else {
+        x[1] = cmul(x[1], w1); x[2] = cmul(x[2], t.w2); x[3] = cmul(x[3], w3); x[4] = cmul(x[4], t.w4);
+        x[5] = cmul(x[5], w5); x[6] = cmul(x[6], w6); x[7] = cmul(x[7], w7);
     }
-    tw.t2[0] = tw.t3[0] = cd{1.0, 0.0};
 }
 
 // Index u of the root zeta^(1+4u) held by (reg, lane) after the forward transform.
@@ -123,24 +152,62 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     dft8<1>(x);
     // exchange 1: (reg m, lane 8b+c) -> (reg b, lane 8m+c)
 #pragma unroll
-    for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];
+    TFHE_XCHG(for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];)
     wave_lds_order();
 #pragma unroll
-    for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
+    TFHE_XCHG(for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];)
     wave_lds_order();
-#pragma unroll
-    for (int b = 1; b < 8; b++) x[b] = cmul(x[b], tw.t2[b]);
+    twist_pow<false>(x, tw.l2);
     dft8<1>(x);
     // exchange 2: (reg m', lane 8m+c) -> (reg c, lane 8m+m')
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];
+    TFHE_XCHG(for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];)
     wave_lds_order();
 #pragma unroll
-    for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
+    TFHE_XCHG(for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];)
     wave_lds_order();
-#pragma unroll
-    for (int c = 1; c < 8; c++) x[c] = cmul(x[c], tw.t3[c]);
+    twist_pow<false>(x, tw.l3);
     dft8<1>(x);
+}
+
+// NB independent forward transforms advanced level by level through ONE scratch buffer: the
+// wave issues write/read pairs of consecutive transforms back to back (its DS operations
+// execute in order, so transform k+1's writes cannot overtake transform k's reads) and only
+// waits when the next level's arithmetic needs the data.  This turns 2*NB exposed LDS round
+// trips into 2 and gives the scheduler NB-way independent fp64 work per level.
+template <int NB>
+__device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, const cd *__restrict__ table,
+                                                     const LaneTwiddles &tw, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+#pragma unroll
+        for (int a = 1; a < 8; a++) x[t][a] = cmul(x[t][a], table[a]);
+        dft8<1>(x[t]);
+#pragma unroll
+        TFHE_XCHG(for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];)
+        wave_lds_order();
+#pragma unroll
+        TFHE_XCHG(for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];)
+        wave_lds_order();
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        twist_pow<false>(x[t], tw.l2);
+        dft8<1>(x[t]);
+#pragma unroll
+        TFHE_XCHG(for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];)
+        wave_lds_order();
+#pragma unroll
+        TFHE_XCHG(for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];)
+        wave_lds_order();
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        twist_pow<false>(x[t], tw.l3);
+        dft8<1>(x[t]);
+    }
 }
 
 // Inverse transform (includes the 1/512 scale); spectrum order in, x[a] = z_{64a+lane} out.
@@ -149,24 +216,22 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
 {
     const int hi = lane >> 3, lo = lane & 7;
     dft8<-1>(x);
-#pragma unroll
-    for (int c = 1; c < 8; c++) x[c] = cmulc(x[c], tw.t3[c]);
+    twist_pow<true>(x, tw.l3);
     // (reg c, lane 8m+m') -> (reg m', lane 8m+c)
 #pragma unroll
-    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    TFHE_XCHG(for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];)
     wave_lds_order();
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    TFHE_XCHG(for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];)
     wave_lds_order();
     dft8<-1>(x);
-#pragma unroll
-    for (int b = 1; b < 8; b++) x[b] = cmulc(x[b], tw.t2[b]);
+    twist_pow<true>(x, tw.l2);
     // (reg b, lane 8m+c) -> (reg m, lane 8b+c)
 #pragma unroll
-    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    TFHE_XCHG(for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];)
     wave_lds_order();
 #pragma unroll
-    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    TFHE_XCHG(for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];)
     wave_lds_order();
     dft8<-1>(x);
 #pragma unroll
