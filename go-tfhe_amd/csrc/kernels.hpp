@@ -382,7 +382,8 @@ __global__ __launch_bounds__(64) void k_bsk_from_torus(const uint32_t *__restric
     for (int k = 0; k < 8; k++) dst[bsk_index(L, i, p, l, part, k, lane)] = x[k];
 }
 
-// Reference KSK [N*t*base][n+1] -> packed [N*t*(base-1)][n1p] (drops the all-zero k = 0 rows).
+// Reference KSK [N*t*base][n+1] -> packed [N*t*(base-1) + 1][n1p] (drops the all-zero k = 0 rows;
+// ONE all-zero row is kept at the end as padding target for the unrolled gather).
 __global__ void k_ksk_pack(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n1, int n1p,
                            int base, size_t rows_packed)
 {
@@ -392,7 +393,7 @@ __global__ void k_ksk_pack(const uint32_t *__restrict__ src, uint32_t *__restric
     const int x = (int)(idx % n1p);
     const size_t ij = row / (base - 1);
     const int k = (int)(row % (base - 1)) + 1;
-    dst[idx] = x < n1 ? src[(ij * base + k) * (size_t)n1 + x] : 0u;
+    dst[idx] = (x < n1 && row + 1 < rows_packed) ? src[(ij * base + k) * (size_t)n1 + x] : 0u;
 }
 
 // ------------------------------------------------------------------------------------
@@ -410,10 +411,11 @@ struct KeySwitchArgs {
     int n, N, t, basebit, n1p;
 };
 
-template <int CH>
+template <int CH, typename IdxT>
 __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
 {
-    __shared__ uint32_t rows[9216];
+    constexpr int U = 8;                      // key rows in flight per wave
+    __shared__ IdxT rows[9216 + 4 * U];
     __shared__ uint32_t red[4][CH * 256];
     __shared__ int count;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -427,24 +429,35 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
         // SampleExtractIndexAssign(.,0,.): P[0] = A[0], P[i] = ~A[N-i]  (trlwe_ops.go:13-19)
         const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
         const uint32_t k = ((ai + prec) >> (32 - (j + 1) * bb)) & (uint32_t)base1;
-        if (k) rows[atomicAdd(&count, 1)] = (uint32_t)idx * base1 + (k - 1);
+        if (k) rows[atomicAdd(&count, 1)] = (IdxT)((uint32_t)idx * base1 + (k - 1));
     }
     __syncthreads();
     const int cnt = count;
+    // pad the list to a multiple of 4*U with the all-zero row appended to the packed key
+    const uint32_t zero_row = (uint32_t)N * t * base1;
+    if (tid < 4 * U) rows[cnt + tid] = (IdxT)zero_row;
+    __syncthreads();
     uint4 acc[CH];
 #pragma unroll
     for (int c = 0; c < CH; c++) acc[c] = make_uint4(0, 0, 0, 0);
     const int quads = A.n1p >> 2;
-    for (int e = w; e < cnt; e += 4) {
-        const uint4 *row = reinterpret_cast<const uint4 *>(A.ksk + (size_t)rows[e] * A.n1p);
+    for (int e = w; e < cnt; e += 4 * U) {
+        uint4 v[U][CH];
 #pragma unroll
-        for (int c = 0; c < CH; c++) {
-            const int qd = c * 64 + lane;
-            if (qd < quads) {
-                const uint4 v = row[qd];
-                acc[c].x += v.x; acc[c].y += v.y; acc[c].z += v.z; acc[c].w += v.w;
+        for (int u = 0; u < U; u++) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(A.ksk + (size_t)rows[e + 4 * u] * A.n1p);
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                const int qd = c * 64 + lane;
+                v[u][c] = qd < quads ? row[qd] : make_uint4(0, 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int c = 0; c < CH; c++) {
+                acc[c].x += v[u][c].x; acc[c].y += v[u][c].y; acc[c].z += v[u][c].z; acc[c].w += v[u][c].w;
+            }
     }
 #pragma unroll
     for (int c = 0; c < CH; c++) {

@@ -116,7 +116,9 @@ __device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &tw, const cd *_
 template <bool CONJ> __device__ __forceinline__ void twist_pow(cd (&x)[8], const TwPow &t)
 {
     cd w1 = t.w1;
+#ifndef TFHE_TW_HOIST
     asm volatile("" : "+v"(w1.re), "+v"(w1.im));
+#endif
     const cd w3 = cmul(w1, t.w2), w5 = cmul(w1, t.w4), w6 = cmul(t.w2, t.w4);
     const cd w7 = cmul(w3, t.w4);
     if (CONJ) {

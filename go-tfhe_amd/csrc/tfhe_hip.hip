@@ -88,7 +88,7 @@ namespace {
 
 size_t bsk_elems(const tfhe_params &P) { return (size_t)P.n * 2 * P.L * 2 * (P.N / 2); }
 size_t ksk_rows_ref(const tfhe_params &P) { return (size_t)P.N * P.t * (1u << P.basebit); }
-size_t ksk_rows_packed(const tfhe_params &P) { return (size_t)P.N * P.t * ((1u << P.basebit) - 1); }
+size_t ksk_rows_packed(const tfhe_params &P) { return (size_t)P.N * P.t * ((1u << P.basebit) - 1); }  // + 1 zero row on device
 
 hipStream_t pick(tfhe_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
 
@@ -181,14 +181,20 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
+    // row indices fit 16 bits for the 2-bit key-switch base of the N=1024 sets (halves the LDS list)
+    const bool small_idx = ksk_rows_packed(c->P) < 65535;
+#define KS_LAUNCH(CH)                                                                                   \
+    if (small_idx) hipLaunchKernelGGL((k_extract_keyswitch<CH, uint16_t>), dim3(B), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((k_extract_keyswitch<CH, uint32_t>), dim3(B), dim3(256), 0, st, a)
     switch (ch) {
-    case 1: hipLaunchKernelGGL((k_extract_keyswitch<1>), dim3(B), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_extract_keyswitch<2>), dim3(B), dim3(256), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((k_extract_keyswitch<3>), dim3(B), dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((k_extract_keyswitch<4>), dim3(B), dim3(256), 0, st, a); break;
-    case 5: hipLaunchKernelGGL((k_extract_keyswitch<5>), dim3(B), dim3(256), 0, st, a); break;
+    case 1: KS_LAUNCH(1); break;
+    case 2: KS_LAUNCH(2); break;
+    case 3: KS_LAUNCH(3); break;
+    case 4: KS_LAUNCH(4); break;
+    case 5: KS_LAUNCH(5); break;
     default: return fail(TFHE_E_INVALID, "LWE dimension %d too large for the key-switch kernel", c->P.n);
     }
+#undef KS_LAUNCH
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(stop, st));
     c->ev_valid[1] = !c->timing;
@@ -380,7 +386,7 @@ int tfhe_load_ksk(tfhe_ctx *c, const uint32_t *ksk)
     std::lock_guard<std::mutex> lk(c->mu);
     const int n1 = c->P.n + 1, base = 1 << c->P.basebit;
     const size_t ref_bytes = ksk_rows_ref(c->P) * n1 * sizeof(uint32_t);
-    const size_t rows_p = ksk_rows_packed(c->P), total = rows_p * c->n1p;
+    const size_t rows_p = ksk_rows_packed(c->P) + 1, total = rows_p * c->n1p;    // + the all-zero padding row
     DevBuf raw;
     if ((rc = raw.reserve(ref_bytes)) || (rc = c->ksk.reserve(total * sizeof(uint32_t)))) { raw.release(); return rc; }
     HIP_TRY(hipMemcpyAsync(raw.p, ksk, ref_bytes, hipMemcpyHostToDevice, c->stream));
