@@ -7,7 +7,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(LIB_DIR, "libtfhe_hip.so")  # env override: kernel experiments
 SOURCES = ["tfhe_hip.hip"]
-HEADERS = ["kernels.hpp", "negacyclic_fft.hpp", os.path.join("..", "..", "include", "tfhe_hip.h")]
+HEADERS = ["kernels.hpp", "kernels_n2048.hpp", "negacyclic_fft.hpp", os.path.join("..", "..", "include", "tfhe_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
 

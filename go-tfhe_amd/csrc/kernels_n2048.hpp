@@ -1,0 +1,296 @@
+// kernels_n2048.hpp -- the same path for N = 2048 rings (Uint5: n=1071, L=1, Bgbit=22;
+// params/params.go:362-391), used by programmable bootstrapping
+// (evaluator/programmable_bootstrap.go:93-115).
+//
+// M = 1024 complex points per polynomial, 16 per lane.  One radix-2 level in registers splits
+// X^1024 - i into X^512 -+ rho (rho = exp(i pi/4)): with j = 64a + lane (a = 0..15) the pair is
+// (a, a+8), so no cross-lane traffic; the two halves h = 0,1 are then independent 512-point
+// trees run by the same fft512_forward/inverse code with their own twiddle tables.  The value
+// left in (half h, reg m'', lane 8m+m') is Z(zeta^(1+4u)), u = h + 2m + 16m' + 128m'',
+// zeta = exp(i pi/2048); the reference keeps that root in FourierPoly slot bitrev10(-u mod 1024).
+//
+// L = 1, so a wave has one forward and one inverse transform per CMUX step and no accumulation
+// across levels: the partner's product goes straight to LDS.  Values reach ~2^58 here, beyond
+// fp64's 53-bit mantissa: like the reference at this parameter set, results are NOT exact
+// integers; the rounding uses the wide form.
+#pragma once
+
+#include "kernels.hpp"
+
+namespace tfhe {
+
+constexpr int kScratchSlots2048 = 1152;   // >= 1024 (partner hand-over of a full spectrum), >= 576 (FFT exchanges)
+
+__host__ __device__ __forceinline__ int spectrum_u_2048(int h, int reg, int lane)
+{
+    return h + 2 * (lane >> 3) + 16 * (lane & 7) + 128 * reg;
+}
+
+__host__ __device__ __forceinline__ int reference_slot_2048(int h, int reg, int lane)
+{
+    int v = (1024 - spectrum_u_2048(h, reg, lane)) & 1023, s = 0;
+#pragma unroll
+    for (int b = 0; b < 10; b++) s |= ((v >> b) & 1) << (9 - b);
+    return s;
+}
+
+// bsk[n][2 (p)][1 (L)][2 (part)][16 (h*8 + reg)][64]
+__host__ __device__ __forceinline__ size_t bsk_index_2048(int i, int p, int part, int hreg, int lane)
+{
+    return ((((size_t)(i * 2 + p)) * 2 + part) * 16 + hreg) * 64 + lane;
+}
+
+struct LaneTwiddles2048 {
+    LaneTwiddles h[2];
+};
+
+__device__ __forceinline__ void load_lane_twiddles_2048(LaneTwiddles2048 &tw, const cd *__restrict__ table, int lane)
+{
+    load_lane_twiddles(tw.h[0], table, lane);
+    load_lane_twiddles(tw.h[1], table + kTwCount1024, lane);
+}
+
+// x[a] = z_{64a+lane}, a = 0..15 in;  out: x[h*8 + m''] in spectrum order.
+__device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *__restrict__ table,
+                                                const LaneTwiddles2048 &tw, int lane)
+{
+    constexpr double r = 0.70710678118654752440;
+    cd y0[8], y1[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        const cd v = x[a + 8];
+        const cd rv = cd{(v.re - v.im) * r, (v.re + v.im) * r};      // rho * v, rho = (1+i)/sqrt2
+        y0[a] = x[a] + rv;                                           // mod X^512 - rho
+        y1[a] = x[a] - rv;                                           // mod X^512 + rho
+    }
+    fft512_forward(y0, sc, table, tw.h[0], lane);
+    fft512_forward(y1, sc, table + kTwCount1024, tw.h[1], lane);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x[k] = y0[k]; x[8 + k] = y1[k]; }
+}
+
+// Inverse; the per-half tables carry conj(c1)/1024, i.e. the 1/512 of each half and the 1/2 of
+// the radix-2 level.
+__device__ __forceinline__ void fft1024_inverse(cd (&x)[16], cd *sc, const cd *__restrict__ table,
+                                                const LaneTwiddles2048 &tw, int lane)
+{
+    constexpr double r = 0.70710678118654752440;
+    cd y0[8], y1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { y0[k] = x[k]; y1[k] = x[8 + k]; }
+    fft512_inverse(y0, sc, table, tw.h[0], lane);
+    fft512_inverse(y1, sc, table + kTwCount1024, tw.h[1], lane);
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        x[a] = y0[a] + y1[a];
+        const cd dlt = y0[a] - y1[a];
+        x[a + 8] = cd{(dlt.re + dlt.im) * r, (dlt.im - dlt.re) * r};  // conj(rho) * (y0 - y1)
+    }
+}
+
+// Polynomial source for the decomposition, N = 2048 flavour of DiffSource.
+__device__ __forceinline__ uint32_t diff_coeff_2048(const uint32_t *accL, int at, const uint32_t *plain, int j)
+{
+    constexpr int N = 2048;
+    if (!accL) return plain[j];
+    const int s = (j - at) & (2 * N - 1);
+    uint32_t v = accL[s & (N - 1)];
+    v ^= 0u - (uint32_t)((s >> 11) & 1);
+    return v - accL[j];
+}
+
+// One external product for L = 1 (evaluator.go:50-81): this wave's half of bsk[i] (x) d.
+template <int BGBIT>
+__device__ __forceinline__ void external_product_core_2048(const uint32_t *accL, int at, const uint32_t *plain,
+                                                           uint32_t (&e)[32], const cd *__restrict__ key_ip,
+                                                           cd *sc_mine, const cd *sc_other, const cd *__restrict__ table,
+                                                           const LaneTwiddles2048 &tw, uint32_t offset, int p, int lane)
+{
+    constexpr uint32_t mask = (1u << BGBIT) - 1u;
+    constexpr int half = 1 << (BGBIT - 1);
+    constexpr int shift = 32 - BGBIT;
+    cd x[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        const uint32_t d0 = diff_coeff_2048(accL, at, plain, 64 * a + lane) + offset;
+        const uint32_t d1 = diff_coeff_2048(accL, at, plain, 64 * a + lane + 1024) + offset;
+        x[a] = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
+    }
+    fft1024_forward(x, sc_mine, table, tw, lane);
+    const cd *kKeep = key_ip + (size_t)(p ? 1 : 0) * 1024 + lane;   // wave p keeps output p
+    const cd *kSend = key_ip + (size_t)(p ? 0 : 1) * 1024 + lane;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        sc_mine[k * 64 + lane] = cmul(x[k], kSend[k * 64]);        // partner's share straight to LDS
+        x[k] = cmul(x[k], kKeep[k * 64]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = x[k] + sc_other[k * 64 + lane];
+    __syncthreads();
+    fft1024_inverse(x, sc_mine, table, tw, lane);
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        e[a] = round_to_torus_wide(x[a].re);
+        e[a + 16] = round_to_torus_wide(x[a].im);
+    }
+}
+
+template <int BGBIT>
+__global__ __launch_bounds__(128, 2) void k_blind_rotate_2048(BlindRotateArgs A)
+{
+    constexpr int N = 2048;
+    __shared__ cd sc[2][kScratchSlots2048];
+    __shared__ uint32_t accL[2][N];
+    __shared__ uint16_t abarL[kMaxLweDim];
+    __shared__ int btL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int item = blockIdx.x;
+    const int n = A.n;
+    {
+        const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
+        const GateCoef g = gate_coef(A.in1 ? op : -1);
+        const uint32_t *x0 = A.in0 + (size_t)item * (n + 1);
+        const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
+        const int sh = 32 - A.Nbit - 1;
+        const uint32_t rnd = 1u << (sh - 1);
+        for (int x = tid; x <= n; x += 128) {
+            uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
+            if (x == n) {
+                v += g.cst;
+                btL = 2 * N - (int)(((unsigned long long)v + rnd) >> sh);
+            } else {
+                abarL[x] = (uint16_t)((uint32_t)(v + rnd) >> sh);
+            }
+        }
+    }
+    LaneTwiddles2048 tw;
+    load_lane_twiddles_2048(tw, A.tw, lane);
+    __syncthreads();
+    {
+        const int bt = btL & (2 * N - 1);
+        const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int j = 64 * q + lane;
+            const int s = (j - bt) & (2 * N - 1);
+            uint32_t v = tv[s & (N - 1)];
+            v ^= 0u - (uint32_t)((s >> 11) & 1);
+            accL[p][j] = v;
+        }
+    }
+    wave_lds_order();
+    const cd *key = A.bsk + (size_t)p * 2 * 1024;
+    constexpr size_t kStep = (size_t)2 * 2 * 1024;
+    for (int i = 0; i < A.nsteps; i++) {
+        const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        uint32_t e[32];
+        external_product_core_2048<BGBIT>(accL[p], at, nullptr, e, key + (size_t)i * kStep, sc[p], sc[p ^ 1], A.tw, tw,
+                                          A.offset, p, lane);
+#pragma unroll
+        for (int q = 0; q < 32; q++) accL[p][64 * q + lane] += e[q];
+        wave_lds_order();
+    }
+    uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
+#pragma unroll
+    for (int q = 0; q < 32; q++) out[64 * q + lane] = accL[p][64 * q + lane];
+}
+
+template <int BGBIT>
+__global__ __launch_bounds__(128, 2) void k_external_product_2048(const cd *bsk, const cd *twt, int key_index,
+                                                                   const uint32_t *in, uint32_t *out, uint32_t offset)
+{
+    constexpr int N = 2048;
+    __shared__ cd sc[2][kScratchSlots2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LaneTwiddles2048 tw;
+    load_lane_twiddles_2048(tw, twt, lane);
+    const uint32_t *src = in + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
+    uint32_t e[32];
+    const cd *key = bsk + ((size_t)key_index * 2 + p) * 2 * 1024;
+    external_product_core_2048<BGBIT>(nullptr, 0, src, e, key, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
+    uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
+#pragma unroll
+    for (int q = 0; q < 32; q++) dst[64 * q + lane] = e[q];
+}
+
+// Reference Fourier layout [n][2][2][2048] float64 -> device layout (L = 1).
+__global__ void k_bsk_from_fourier_2048(const double *__restrict__ src, cd *__restrict__ dst, int n)
+{
+    const size_t total = (size_t)n * 2 * 2 * 1024;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, hreg = (idx >> 6) & 15, part = (idx >> 10) & 1;
+    const size_t ip = idx >> 11;                 // i*2 + p ; reference row r = p (L = 1)
+    const double *poly = src + (ip * 2 + part) * 2048;
+    const int s = reference_slot_2048(hreg >> 3, hreg & 7, lane);
+    const int base = 8 * (s >> 2) + (s & 3);
+    dst[idx] = cd{poly[base], poly[base + 4]};
+}
+
+__global__ __launch_bounds__(64) void k_bsk_from_torus_2048(const uint32_t *__restrict__ src, cd *__restrict__ dst,
+                                                             const cd *__restrict__ twt)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x;
+    const int polyIdx = blockIdx.x;              // ((i*2 + r)*2 + part), r = p
+    LaneTwiddles2048 tw;
+    load_lane_twiddles_2048(tw, twt, lane);
+    const uint32_t *poly = src + (size_t)polyIdx * 2048;
+    cd x[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++)
+        x[a] = cd{(double)(int32_t)poly[64 * a + lane], (double)(int32_t)poly[64 * a + lane + 1024]};
+    fft1024_forward(x, sc, twt, tw, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) dst[((size_t)polyIdx * 16 + k) * 64 + lane] = x[k];
+}
+
+__global__ __launch_bounds__(64) void k_to_fourier_2048(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
+                                                         const cd *__restrict__ twt)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x;
+    LaneTwiddles2048 tw;
+    load_lane_twiddles_2048(tw, twt, lane);
+    const uint32_t *poly = polys + (size_t)blockIdx.x * 2048;
+    double *fp = spectra + (size_t)blockIdx.x * 2048;
+    cd x[16];
+#pragma unroll
+    for (int a = 0; a < 16; a++)
+        x[a] = cd{(double)(int32_t)poly[64 * a + lane], (double)(int32_t)poly[64 * a + lane + 1024]};
+    fft1024_forward(x, sc, twt, tw, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int s = reference_slot_2048(k >> 3, k & 7, lane), base = 8 * (s >> 2) + (s & 3);
+        fp[base] = x[k].re;
+        fp[base + 4] = x[k].im;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_to_poly_2048(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
+                                                      const cd *__restrict__ twt)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x;
+    LaneTwiddles2048 tw;
+    load_lane_twiddles_2048(tw, twt, lane);
+    const double *fp = spectra + (size_t)blockIdx.x * 2048;
+    uint32_t *poly = polys + (size_t)blockIdx.x * 2048;
+    cd x[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int s = reference_slot_2048(k >> 3, k & 7, lane), base = 8 * (s >> 2) + (s & 3);
+        x[k] = cd{fp[base], fp[base + 4]};
+    }
+    fft1024_inverse(x, sc, twt, tw, lane);
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        poly[64 * a + lane] = round_to_torus_wide(x[a].re);
+        poly[64 * a + lane + 1024] = round_to_torus_wide(x[a].im);
+    }
+}
+
+} // namespace tfhe

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "kernels_n2048.hpp"
 
 using namespace tfhe;
 
@@ -92,27 +93,34 @@ size_t ksk_rows_packed(const tfhe_params &P) { return (size_t)P.N * P.t * ((1u <
 
 hipStream_t pick(tfhe_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
 
-// Twiddle table for N = 1024 (negacyclic_fft.hpp), computed in long double.
-std::vector<cd> make_twiddles_1024()
+// Twiddle tables (negacyclic_fft.hpp layout), computed in long double.  One table per half h of
+// the ring's root tree: N = 1024 has one (H = 1), N = 2048 two (H = 2, kernels_n2048.hpp).  The
+// root index is u = h + H*(m + 8m' + 64m''); the level-k pre-twist is zeta^(stride * idx * (1 + 4 u_k))
+// with u_k the part of u already fixed at that level and zeta = exp(i pi / N).
+std::vector<cd> make_twiddles(int N)
 {
-    std::vector<cd> t(kTwCount1024);
+    const int H = N / 1024;
+    std::vector<cd> t((size_t)kTwCount1024 * H);
     const long double pi = 3.14159265358979323846264338327950288L;
-    auto zeta = [&](long e) {               // zeta^e, zeta = exp(i pi / 1024)
-        e %= 2048; if (e < 0) e += 2048;
-        long double a = pi * (long double)e / 1024.0L;
+    auto zeta = [&](long e) {
+        e %= 2L * N; if (e < 0) e += 2L * N;
+        long double a = pi * (long double)e / (long double)N;
         return cd{(double)cosl(a), (double)sinl(a)};
     };
-    for (int a = 0; a < 8; a++) {
-        t[a] = zeta(64L * a);
-        cd c = zeta(-64L * a);
-        t[8 + a] = cd{c.re / 512.0, c.im / 512.0};
-    }
-    for (int k = 0; k < 8; k++)
-        for (int lane = 0; lane < 64; lane++) {
-            const int m = lane >> 3, mp = lane & 7;
-            t[kTwLevel2 + k * 64 + lane] = zeta(8L * k * (1 + 4 * m));
-            t[kTwLevel3 + k * 64 + lane] = zeta((long)k * (1 + 4 * (m + 8 * mp)));
+    for (int h = 0; h < H; h++) {
+        cd *T = t.data() + (size_t)h * kTwCount1024;
+        for (int a = 0; a < 8; a++) {
+            T[a] = zeta(64L * a * (1 + 4 * h));
+            cd c = zeta(-64L * a * (1 + 4 * h));
+            T[8 + a] = cd{c.re / (512.0 * H), c.im / (512.0 * H)};
         }
+        for (int k = 0; k < 8; k++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int m = lane >> 3, mp = lane & 7;
+                T[kTwLevel2 + k * 64 + lane] = zeta(8L * k * (1 + 4 * (h + H * m)));
+                T[kTwLevel3 + k * 64 + lane] = zeta((long)k * (1 + 4 * (h + H * (m + 8 * mp))));
+            }
+    }
     return t;
 }
 
@@ -163,7 +171,7 @@ int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in
     if (c->shape == 1)
         hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a);
     else
-        return fail(TFHE_E_INVALID, "parameter shape %d has no blind-rotate kernel", c->shape);
+        hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(128), 0, st, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(stop, st));
     c->ev_valid[0] = !c->timing;
@@ -278,8 +286,10 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     if (!P || !out) return fail(TFHE_E_INVALID, "null argument");
     int shape = 0;
     if (P->N == 1024 && P->Nbit == 10 && P->L == 3 && P->Bgbit == 6) shape = 1;
+    if (P->N == 2048 && P->Nbit == 11 && P->L == 1 && P->Bgbit == 22) shape = 2;
     if (!shape)
-        return fail(TFHE_E_INVALID, "unsupported parameter shape N=%d L=%d Bgbit=%d (supported: N=1024,L=3,Bgbit=6)",
+        return fail(TFHE_E_INVALID,
+                    "unsupported parameter shape N=%d L=%d Bgbit=%d (supported: N=1024,L=3,Bgbit=6 and N=2048,L=1,Bgbit=22)",
                     P->N, P->L, P->Bgbit);
     if (P->n < 1 || P->n >= kMaxLweDim) return fail(TFHE_E_INVALID, "LWE dimension %d out of range", P->n);
     if (P->basebit < 1 || P->t < 1 || P->basebit * P->t > 31 || (size_t)P->N * P->t > 9216)
@@ -295,7 +305,7 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
-    std::vector<cd> tw = make_twiddles_1024();
+    std::vector<cd> tw = make_twiddles(P->N);
     int rc;
     if ((rc = c->tw.reserve(tw.size() * sizeof(cd)))) { delete c; return rc; }
     HIP_TRY(hipMemcpy(c->tw.p, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
@@ -350,8 +360,12 @@ int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
     DevBuf raw;
     if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bytes))) { raw.release(); return rc; }
     HIP_TRY(hipMemcpyAsync(raw.p, bsk, bytes, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_bsk_from_fourier, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
-                       raw.as<double>(), c->bsk.as<cd>(), c->P.n, c->P.L);
+    if (c->shape == 1)
+        hipLaunchKernelGGL(k_bsk_from_fourier, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                           raw.as<double>(), c->bsk.as<cd>(), c->P.n, c->P.L);
+    else
+        hipLaunchKernelGGL(k_bsk_from_fourier_2048, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                           raw.as<double>(), c->bsk.as<cd>(), c->P.n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     raw.release();
@@ -369,8 +383,12 @@ int tfhe_load_bsk_torus(tfhe_ctx *c, const uint32_t *bsk)
     DevBuf raw;
     if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bsk_elems(c->P) * sizeof(cd)))) { raw.release(); return rc; }
     HIP_TRY(hipMemcpyAsync(raw.p, bsk, bytes, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_bsk_from_torus, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
-                       c->bsk.as<cd>(), c->tw.as<cd>(), c->P.L);
+    if (c->shape == 1)
+        hipLaunchKernelGGL(k_bsk_from_torus, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
+                           c->bsk.as<cd>(), c->tw.as<cd>(), c->P.L);
+    else
+        hipLaunchKernelGGL(k_bsk_from_torus_2048, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
+                           c->bsk.as<cd>(), c->tw.as<cd>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     raw.release();
@@ -542,8 +560,12 @@ int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, 
     const size_t trl = (size_t)B * 2 * c->P.N * 4;
     if ((rc = c->s_trlwe.reserve(trl)) || (rc = c->s_t0.reserve(trl))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, c->stream, c->bsk.as<cd>(), c->tw.as<cd>(),
-                       key_index, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->offset);
+    if (c->shape == 1)
+        hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, c->stream, c->bsk.as<cd>(), c->tw.as<cd>(),
+                           key_index, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->offset);
+    else
+        hipLaunchKernelGGL((k_external_product_2048<22>), dim3(B), dim3(128), 0, c->stream, c->bsk.as<cd>(),
+                           c->tw.as<cd>(), key_index, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->offset);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->s_t0.p, trl, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -560,8 +582,12 @@ int tfhe_to_fourier_batch(tfhe_ctx *c, const uint32_t *polys, double *spectra, i
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
     if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t0.p, polys, pb, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_to_fourier, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(), c->s_t1.as<double>(),
-                       c->tw.as<cd>());
+    if (c->shape == 1)
+        hipLaunchKernelGGL(k_to_fourier, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(), c->s_t1.as<double>(),
+                           c->tw.as<cd>());
+    else
+        hipLaunchKernelGGL(k_to_fourier_2048, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(),
+                           c->s_t1.as<double>(), c->tw.as<cd>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(spectra, c->s_t1.p, sb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -578,8 +604,12 @@ int tfhe_to_poly_batch(tfhe_ctx *c, const double *spectra, uint32_t *polys, int 
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
     if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t1.p, spectra, sb, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_to_poly, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
-                       c->tw.as<cd>());
+    if (c->shape == 1)
+        hipLaunchKernelGGL(k_to_poly, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
+                           c->tw.as<cd>());
+    else
+        hipLaunchKernelGGL(k_to_poly_2048, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
+                           c->tw.as<cd>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(polys, c->s_t0.p, pb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
