@@ -137,7 +137,7 @@ __device__ __forceinline__ void external_product_core_2048(const uint32_t *accL,
 }
 
 template <int BGBIT>
-__global__ __launch_bounds__(128, 2) void k_blind_rotate_2048(BlindRotateArgs A)
+__global__ __launch_bounds__(128) void k_blind_rotate_2048(BlindRotateArgs A)
 {
     constexpr int N = 2048;
     __shared__ cd sc[2][kScratchSlots2048];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate_2048(BlindRotateArgs A)
 }
 
 template <int BGBIT>
-__global__ __launch_bounds__(128, 2) void k_external_product_2048(const cd *bsk, const cd *twt, int key_index,
+__global__ __launch_bounds__(128) void k_external_product_2048(const cd *bsk, const cd *twt, int key_index,
                                                                    const uint32_t *in, uint32_t *out, uint32_t offset)
 {
     constexpr int N = 2048;

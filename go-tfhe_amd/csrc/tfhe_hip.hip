@@ -91,7 +91,8 @@ size_t bsk_elems(const tfhe_params &P) { return (size_t)P.n * 2 * P.L * 2 * (P.N
 size_t ksk_rows_ref(const tfhe_params &P) { return (size_t)P.N * P.t * (1u << P.basebit); }
 size_t ksk_rows_packed(const tfhe_params &P) { return (size_t)P.N * P.t * ((1u << P.basebit) - 1); }  // + 1 zero row on device
 
-hipStream_t pick(tfhe_ctx *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+// _dev entry points run on the caller's stream; NULL is HIP's default (null) stream, as for any hipStream_t.
+hipStream_t pick(tfhe_ctx *, void *stream) { return (hipStream_t)stream; }
 
 // Twiddle tables (negacyclic_fft.hpp layout), computed in long double.  One table per half h of
 // the ring's root tree: N = 1024 has one (H = 1), N = 2048 two (H = 2, kernels_n2048.hpp).  The
@@ -517,7 +518,7 @@ int tfhe_bootstrap_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, in
     HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
     if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
     if ((rc = tfhe_bootstrap_batch_dev(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
-                                       c->s_out.as<uint32_t>(), B, nullptr))) return rc;
+                                       c->s_out.as<uint32_t>(), B, (void *)c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;

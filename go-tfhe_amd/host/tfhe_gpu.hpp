@@ -1,0 +1,249 @@
+// tfhe_gpu.hpp -- C++ host side above the C ABI, mirroring go-tfhe's operator packages.
+//
+// The reference is Go; this image has no Go toolchain, so the host layer a Go user would call
+// is provided in C++ with the same package / function names, argument meaning and error
+// behaviour (a Go panic becomes a thrown tfhe::Panic).  Namespaces = Go packages:
+//
+//   params::     parameter sets                     (params/params.go:83-112,117-146,151-180,362-391)
+//   tlwe::       TLWELv0 sample + linear ops        (tlwe/tlwe.go:11-33,76-134)
+//   trlwe::      TRLWELv1 sample                    (trlwe/trlwe.go:13-25)
+//   cloudkey::   CloudKey resident on one GPU       (cloudkey/cloudkey.go:16-31)
+//   evaluator::  Evaluator {ExternalProductAssign, BlindRotateAssign, BootstrapAssign, Bootstrap,
+//                BootstrapLUTAssign, Prepare*}      (evaluator/evaluator.go:50-157, gates_helper.go:10-63,
+//                                                    programmable_bootstrap.go:54-115)
+//   gates::      NAND ... MUX, NOT, Copy, Constant, Batch*   (gates/gates.go:26-126,156-312)
+//
+// Header-only; link with -ltfhe_hip.  Everything that computes goes through include/tfhe_hip.h.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tfhe_hip.h"
+
+namespace tfhe {
+
+struct Panic : std::runtime_error {
+    int code;
+    Panic(int c, const std::string &m) : std::runtime_error("tfhe_hip: " + m), code(c) {}
+};
+
+inline void check(int rc)
+{
+    if (rc != TFHE_OK) throw Panic(rc, tfhe_last_error());
+}
+
+namespace params {
+using Torus = uint32_t;                                   // params.go:27
+using Params = tfhe_params;
+inline Params Security80Bit() { return {550, 1024, 10, 3, 6, 2, 7}; }
+inline Params Security110Bit() { return {630, 1024, 10, 3, 6, 2, 8}; }
+inline Params Security128Bit() { return {700, 1024, 10, 3, 6, 2, 9}; }
+inline Params SecurityUint5() { return {1071, 2048, 11, 1, 22, 6, 3}; }
+} // namespace params
+
+namespace tlwe {
+// tlwe.go:11-33 : n+1 words, body last.
+struct TLWELv0 {
+    std::vector<params::Torus> P;
+    TLWELv0() = default;
+    explicit TLWELv0(int n) : P((size_t)n + 1, 0u) {}
+    params::Torus B() const { return P.back(); }
+    void SetB(params::Torus v) { P.back() = v; }
+    // tlwe.go:76-134
+    TLWELv0 Add(const TLWELv0 &o) const { TLWELv0 r = *this; for (size_t i = 0; i < P.size(); i++) r.P[i] = P[i] + o.P[i]; return r; }
+    TLWELv0 Sub(const TLWELv0 &o) const { TLWELv0 r = *this; for (size_t i = 0; i < P.size(); i++) r.P[i] = P[i] - o.P[i]; return r; }
+    TLWELv0 Neg() const { TLWELv0 r = *this; for (auto &x : r.P) x = 0u - x; return r; }
+    TLWELv0 AddMul(const TLWELv0 &o, params::Torus m) const { TLWELv0 r = *this; for (size_t i = 0; i < P.size(); i++) r.P[i] = P[i] + o.P[i] * m; return r; }
+    TLWELv0 SubMul(const TLWELv0 &o, params::Torus m) const { TLWELv0 r = *this; for (size_t i = 0; i < P.size(); i++) r.P[i] = P[i] - o.P[i] * m; return r; }
+};
+} // namespace tlwe
+
+namespace trlwe {
+// trlwe.go:13-16
+struct TRLWELv1 {
+    std::vector<params::Torus> A, B;
+    TRLWELv1() = default;
+    explicit TRLWELv1(int N) : A((size_t)N, 0u), B((size_t)N, 0u) {}
+};
+} // namespace trlwe
+
+namespace cloudkey {
+// cloudkey.go:16-21.  DecompositionOffset and BlindRotateTestvec are derived from the
+// parameters inside the context; the two keys are uploaded once from flat arrays.
+class CloudKey {
+  public:
+    // bsk_fourier: [n][2L][2][N] float64 in the reference FourierPoly layout; ksk: [N*t*base][n+1].
+    CloudKey(const params::Params &p, const double *bsk_fourier, const uint32_t *ksk, int device = 0) : P(p)
+    {
+        check(tfhe_ctx_create(&P, device, &ctx_));
+        if (bsk_fourier) check(tfhe_load_bsk_fourier(ctx_, bsk_fourier));
+        if (ksk) check(tfhe_load_ksk(ctx_, ksk));
+    }
+    // coefficient-domain bootstrapping key (trgsw.TRGSWLv1), [n][2L][2][N] uint32
+    static std::unique_ptr<CloudKey> FromTorus(const params::Params &p, const uint32_t *bsk_torus, const uint32_t *ksk, int device = 0)
+    {
+        auto ck = std::make_unique<CloudKey>(p, nullptr, ksk, device);
+        check(tfhe_load_bsk_torus(ck->ctx_, bsk_torus));
+        return ck;
+    }
+    ~CloudKey() { if (ctx_) tfhe_ctx_destroy(ctx_); }
+    CloudKey(const CloudKey &) = delete;
+    CloudKey &operator=(const CloudKey &) = delete;
+    tfhe_ctx *ctx() const { return ctx_; }
+    params::Params P;
+
+  private:
+    tfhe_ctx *ctx_ = nullptr;
+};
+} // namespace cloudkey
+
+namespace detail {
+inline std::vector<uint32_t> flatten(const std::vector<tlwe::TLWELv0> &v, size_t n1)
+{
+    std::vector<uint32_t> f(v.size() * n1);
+    for (size_t i = 0; i < v.size(); i++) {
+        if (v[i].P.size() != n1) throw Panic(TFHE_E_INVALID, "ciphertext has the wrong length");
+        std::copy(v[i].P.begin(), v[i].P.end(), f.begin() + i * n1);
+    }
+    return f;
+}
+inline std::vector<tlwe::TLWELv0> unflatten(const std::vector<uint32_t> &f, size_t n1)
+{
+    std::vector<tlwe::TLWELv0> v(f.size() / n1);
+    for (size_t i = 0; i < v.size(); i++) v[i].P.assign(f.begin() + i * n1, f.begin() + (i + 1) * n1);
+    return v;
+}
+} // namespace detail
+
+namespace evaluator {
+// evaluator.go:14-35.  The bsk / ksk / decompositionOffset arguments of the Go methods are the
+// ones resident in the CloudKey; outputs are caller-owned (the *Assign style).
+class Evaluator {
+  public:
+    explicit Evaluator(const cloudkey::CloudKey &ck) : ck_(ck), n1_((size_t)ck.P.n + 1) {}
+
+    // evaluator.go:50-81 : ctOut = bsk[keyIndex] (x) ctIn
+    void ExternalProductAssign(int keyIndex, const trlwe::TRLWELv1 &ctIn, trlwe::TRLWELv1 &ctOut) const
+    {
+        const size_t N = (size_t)ck_.P.N;
+        std::vector<uint32_t> in(2 * N), out(2 * N);
+        std::copy(ctIn.A.begin(), ctIn.A.end(), in.begin());
+        std::copy(ctIn.B.begin(), ctIn.B.end(), in.begin() + N);
+        check(tfhe_external_product_batch(ck_.ctx(), keyIndex, in.data(), out.data(), 1));
+        ctOut.A.assign(out.begin(), out.begin() + N);
+        ctOut.B.assign(out.begin() + N, out.end());
+    }
+    // evaluator.go:110-135 ; testvec == nullptr selects the gate test vector (cloudkey.go:74-85)
+    void BlindRotateAssign(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 *testvec, trlwe::TRLWELv1 &ctOut) const
+    {
+        const size_t N = (size_t)ck_.P.N;
+        std::vector<uint32_t> tv, out(2 * N);
+        if (testvec) { tv = testvec->A; tv.insert(tv.end(), testvec->B.begin(), testvec->B.end()); }
+        check(tfhe_blind_rotate_batch(ck_.ctx(), ctIn.P.data(), testvec ? tv.data() : nullptr, 0, out.data(), 1, -1));
+        ctOut.A.assign(out.begin(), out.begin() + N);
+        ctOut.B.assign(out.begin() + N, out.end());
+    }
+    // evaluator.go:139-148
+    void BootstrapAssign(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 *testvec, tlwe::TLWELv0 &ctOut) const
+    {
+        std::vector<uint32_t> tv;
+        if (testvec) { tv = testvec->A; tv.insert(tv.end(), testvec->B.begin(), testvec->B.end()); }
+        ctOut.P.resize(n1_);
+        check(tfhe_bootstrap_batch(ck_.ctx(), ctIn.P.data(), testvec ? tv.data() : nullptr, 0, ctOut.P.data(), 1));
+    }
+    // evaluator.go:152-157 (returns an owned value, not a pointer into a 4-slot pool)
+    tlwe::TLWELv0 Bootstrap(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 *testvec = nullptr) const
+    {
+        tlwe::TLWELv0 out;
+        BootstrapAssign(ctIn, testvec, out);
+        return out;
+    }
+    // programmable_bootstrap.go:93-115 : the LUT is a TRLWE with A = 0, B = table
+    void BootstrapLUTAssign(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 &lut, tlwe::TLWELv0 &ctOut) const { BootstrapAssign(ctIn, &lut, ctOut); }
+    tlwe::TLWELv0 BootstrapLUT(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 &lut) const { return Bootstrap(ctIn, &lut); }
+    // batch forms (trgsw.go:234-252)
+    std::vector<tlwe::TLWELv0> BatchBootstrap(const std::vector<tlwe::TLWELv0> &in, const trlwe::TRLWELv1 *testvec = nullptr) const
+    {
+        std::vector<uint32_t> tv, f = detail::flatten(in, n1_), out(f.size());
+        if (testvec) { tv = testvec->A; tv.insert(tv.end(), testvec->B.begin(), testvec->B.end()); }
+        check(tfhe_bootstrap_batch(ck_.ctx(), f.data(), testvec ? tv.data() : nullptr, 0, out.data(), (int)in.size()));
+        return detail::unflatten(out, n1_);
+    }
+    // gates_helper.go:10-63 (the GPU path fuses these; kept for the Prepare + Bootstrap seam)
+    tlwe::TLWELv0 PrepareNAND(const tlwe::TLWELv0 &a, const tlwe::TLWELv0 &b) const { auto r = a.Add(b).Neg(); r.SetB(r.B() + 0x20000000u); return r; }
+    tlwe::TLWELv0 PrepareAND(const tlwe::TLWELv0 &a, const tlwe::TLWELv0 &b) const { auto r = a.Add(b); r.SetB(r.B() + 0xE0000000u); return r; }
+    tlwe::TLWELv0 PrepareOR(const tlwe::TLWELv0 &a, const tlwe::TLWELv0 &b) const { auto r = a.Add(b); r.SetB(r.B() + 0x20000000u); return r; }
+    tlwe::TLWELv0 PrepareXOR(const tlwe::TLWELv0 &a, const tlwe::TLWELv0 &b) const { auto r = a.AddMul(b, 2); r.SetB(r.B() + 0x40000000u); return r; }
+
+  private:
+    const cloudkey::CloudKey &ck_;
+    size_t n1_;
+};
+} // namespace evaluator
+
+namespace gates {
+using Ciphertext = tlwe::TLWELv0;                         // gates.go:16
+
+namespace detail_g {
+inline std::vector<Ciphertext> run(int op, const std::vector<Ciphertext> &a, const std::vector<Ciphertext> &b,
+                                   const std::vector<Ciphertext> *c, const cloudkey::CloudKey &ck)
+{
+    const size_t n1 = (size_t)ck.P.n + 1;
+    if (a.size() != b.size() || (c && c->size() != a.size())) throw Panic(TFHE_E_INVALID, "operand counts differ");
+    std::vector<uint32_t> fa = detail::flatten(a, n1), fb = detail::flatten(b, n1), fc, out(fa.size());
+    if (c) fc = detail::flatten(*c, n1);
+    check(tfhe_gate_batch(ck.ctx(), nullptr, op, fa.data(), fb.data(), c ? fc.data() : nullptr, out.data(), (int)a.size()));
+    return detail::unflatten(out, n1);
+}
+inline Ciphertext one(int op, const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return run(op, {a}, {b}, nullptr, ck)[0]; }
+inline std::vector<Ciphertext> batch(int op, const std::vector<std::array<Ciphertext, 2>> &in, const cloudkey::CloudKey &ck)
+{
+    std::vector<Ciphertext> a, b;
+    for (auto &p : in) { a.push_back(p[0]); b.push_back(p[1]); }
+    return run(op, a, b, nullptr, ck);
+}
+} // namespace detail_g
+
+// gates.go:26-104
+inline Ciphertext NAND(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_NAND, a, b, ck); }
+inline Ciphertext OR(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_OR, a, b, ck); }
+inline Ciphertext AND(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_AND, a, b, ck); }
+inline Ciphertext XOR(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_XOR, a, b, ck); }
+inline Ciphertext XNOR(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_XNOR, a, b, ck); }
+inline Ciphertext NOR(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_NOR, a, b, ck); }
+inline Ciphertext ANDNY(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_ANDNY, a, b, ck); }
+inline Ciphertext ANDYN(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_ANDYN, a, b, ck); }
+inline Ciphertext ORNY(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_ORNY, a, b, ck); }
+inline Ciphertext ORYN(const Ciphertext &a, const Ciphertext &b, const cloudkey::CloudKey &ck) { return detail_g::one(TFHE_OP_ORYN, a, b, ck); }
+// gates.go:107-114 : a ? b : c, three bootstraps
+inline Ciphertext MUX(const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const cloudkey::CloudKey &ck)
+{
+    std::vector<Ciphertext> cv{c};
+    return detail_g::run(TFHE_OP_MUX, {a}, {b}, &cv, ck)[0];
+}
+inline Ciphertext NOT(const Ciphertext &a) { return a.Neg(); }                 // gates.go:117-119
+inline Ciphertext Copy(const Ciphertext &a) { return a; }                      // gates.go:122-126
+inline Ciphertext Constant(bool value, const params::Params &p)                // gates.go:61-69 (keeps the reference's 1 - mu)
+{
+    Ciphertext r(p.n);
+    const uint32_t mu = 0x20000000u;
+    r.SetB(value ? mu : 1u - mu);
+    return r;
+}
+// gates.go:156-312 ([][2]*Ciphertext -> []*Ciphertext).  BatchXNOR follows the scalar XNOR sign.
+using Pairs = std::vector<std::array<Ciphertext, 2>>;
+inline std::vector<Ciphertext> BatchNAND(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_NAND, in, ck); }
+inline std::vector<Ciphertext> BatchAND(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_AND, in, ck); }
+inline std::vector<Ciphertext> BatchOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_OR, in, ck); }
+inline std::vector<Ciphertext> BatchXOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_XOR, in, ck); }
+inline std::vector<Ciphertext> BatchNOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_NOR, in, ck); }
+inline std::vector<Ciphertext> BatchXNOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_XNOR, in, ck); }
+} // namespace gates
+
+} // namespace tfhe

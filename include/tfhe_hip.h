@@ -15,9 +15,10 @@
  *     (evaluator.go:14-24: "not goroutine-safe"); use one context per GPU/goroutine.
  *   - keys are copied at load time and are immutable afterwards.
  *   - outputs are caller-owned (the *Assign style of the reference).
- *   - "_dev" variants take DEVICE pointers and a hipStream_t (as void*; NULL = the
- *     context's own stream) and only enqueue work; the others take HOST pointers and
- *     return after the result is in the output buffer.
+ *   - "_dev" variants take DEVICE pointers and a hipStream_t (as void*; NULL = HIP's
+ *     default stream, as for any hipStream_t) and only enqueue work on that stream, ordered
+ *     with the caller's other work there; the others take HOST pointers, run on the
+ *     context's private stream and return after the result is in the output buffer.
  *   - all ciphertext words are uint32 torus values (params.Torus, params.go:27);
  *     an LWE sample is n+1 words with the body LAST (tlwe.go:11-33); a TRLWE sample is
  *     [2][N] words, A then B (trlwe.go:13-16).

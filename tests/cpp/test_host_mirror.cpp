@@ -1,0 +1,106 @@
+// C++ host-mirror test (runs on the GPU box): the reference's own gate tests re-expressed
+// against tfhe::gates / tfhe::evaluator (gates/gates_test.go:23-366, 369-480), with the CPU
+// oracle (test infrastructure) as key generator, encryptor/decryptor and bit-exact checker.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../go-tfhe_amd/host/tfhe_gpu.hpp"
+#include "../../oracle/tfhe_oracle.h"
+
+using namespace tfhe;
+
+static int failures = 0;
+#define EXPECT(cond, ...) do { if (!(cond)) { failures++; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+
+int main()
+{
+    orc_params op;
+    orc_get_params(0, &op);                                   // 80-bit set (via explicit params)
+    params::Params p = params::Security80Bit();
+    orc_rng rng;
+    orc_rng_seed(&rng, 0x7F4E0021ull);
+    std::vector<uint32_t> s0(op.n), s1(op.N);
+    orc_keygen_secret(&op, &rng, s0.data(), s1.data());
+    const size_t bsk_len = (size_t)op.n * 2 * op.L * 2 * op.N;
+    std::vector<double> bsk(bsk_len);
+    orc_keygen_bsk(&op, &rng, s0.data(), s1.data(), nullptr, bsk.data());
+    std::vector<uint32_t> ksk((size_t)op.N * op.t * (1 << op.basebit) * (op.n + 1));
+    orc_keygen_ksk(&op, &rng, s0.data(), s1.data(), ksk.data());
+    orc_fft *fft = orc_fft_new(op.N);
+
+    cloudkey::CloudKey ck(p, bsk.data(), ksk.data(), 0);
+    auto enc = [&](int bit) { gates::Ciphertext c(op.n); orc_tlwe_encrypt_bool(&op, &rng, bit, s0.data(), c.P.data()); return c; };
+    auto dec = [&](const gates::Ciphertext &c) { return orc_tlwe_decrypt_bool(&op, s0.data(), c.P.data()) != 0; };
+
+    struct G { const char *name; gates::Ciphertext (*f)(const gates::Ciphertext &, const gates::Ciphertext &, const cloudkey::CloudKey &); int op; bool (*t)(bool, bool); };
+    const G table[] = {
+        {"NAND", gates::NAND, ORC_NAND, [](bool a, bool b) { return !(a && b); }},
+        {"AND", gates::AND, ORC_AND, [](bool a, bool b) { return a && b; }},
+        {"OR", gates::OR, ORC_OR, [](bool a, bool b) { return a || b; }},
+        {"XOR", gates::XOR, ORC_XOR, [](bool a, bool b) { return a != b; }},
+        {"XNOR", gates::XNOR, ORC_XNOR, [](bool a, bool b) { return a == b; }},
+        {"NOR", gates::NOR, ORC_NOR, [](bool a, bool b) { return !(a || b); }},
+        {"ANDNY", gates::ANDNY, ORC_ANDNY, [](bool a, bool b) { return !a && b; }},
+        {"ANDYN", gates::ANDYN, ORC_ANDYN, [](bool a, bool b) { return a && !b; }},
+        {"ORNY", gates::ORNY, ORC_ORNY, [](bool a, bool b) { return !a || b; }},
+        {"ORYN", gates::ORYN, ORC_ORYN, [](bool a, bool b) { return a || !b; }},
+    };
+    for (const G &g : table)
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                auto ca = enc(a), cb = enc(b);
+                auto out = g.f(ca, cb, ck);
+                EXPECT(dec(out) == g.t(a, b), "%s(%d,%d) decrypts wrong", g.name, a, b);
+                std::vector<uint32_t> want(op.n + 1);
+                orc_gate(&op, fft, bsk.data(), ksk.data(), g.op, ca.P.data(), cb.P.data(), nullptr, want.data());
+                EXPECT(out.P == want, "%s(%d,%d) differs from the oracle", g.name, a, b);
+            }
+    // MUX, NOT, Copy, Constant (gates_test.go:273-366)
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++)
+            for (int c = 0; c < 2; c++) {
+                auto out = gates::MUX(enc(a), enc(b), enc(c), ck);
+                EXPECT(dec(out) == (a ? b : c), "MUX(%d,%d,%d)", a, b, c);
+            }
+    EXPECT(dec(gates::NOT(enc(1))) == false && dec(gates::NOT(enc(0))) == true, "NOT");
+    EXPECT(dec(gates::Copy(enc(1))) == true, "Copy");
+    EXPECT(dec(gates::Constant(true, p)) == true && dec(gates::Constant(false, p)) == false, "Constant");
+    // Batch AND/OR/XOR with 4 inputs (gates_test.go:369-480) + NAND/NOR/XNOR (untested upstream)
+    gates::Pairs pairs;
+    const int A[4] = {0, 0, 1, 1}, B[4] = {0, 1, 0, 1};
+    for (int i = 0; i < 4; i++) pairs.push_back({enc(A[i]), enc(B[i])});
+    auto r_and = gates::BatchAND(pairs, ck), r_or = gates::BatchOR(pairs, ck), r_xor = gates::BatchXOR(pairs, ck);
+    auto r_nand = gates::BatchNAND(pairs, ck), r_nor = gates::BatchNOR(pairs, ck), r_xnor = gates::BatchXNOR(pairs, ck);
+    for (int i = 0; i < 4; i++) {
+        EXPECT(dec(r_and[i]) == (A[i] && B[i]), "BatchAND %d", i);
+        EXPECT(dec(r_or[i]) == (A[i] || B[i]), "BatchOR %d", i);
+        EXPECT(dec(r_xor[i]) == (A[i] != B[i]), "BatchXOR %d", i);
+        EXPECT(dec(r_nand[i]) == !(A[i] && B[i]), "BatchNAND %d", i);
+        EXPECT(dec(r_nor[i]) == !(A[i] || B[i]), "BatchNOR %d", i);
+        EXPECT(dec(r_xnor[i]) == (A[i] == B[i]), "BatchXNOR %d", i);
+    }
+    // Prepare + Bootstrap seam (BASELINE config 1 goes through this)
+    evaluator::Evaluator ev(ck);
+    auto ca = enc(1), cb = enc(1);
+    EXPECT(dec(ev.Bootstrap(ev.PrepareNAND(ca, cb))) == false, "PrepareNAND + Bootstrap");
+    EXPECT(dec(ev.Bootstrap(ev.PrepareXOR(ca, cb))) == false, "PrepareXOR + Bootstrap");
+    // BlindRotateAssign + test-vector variant are bit-exact vs the oracle
+    trlwe::TRLWELv1 acc(op.N);
+    auto prep = ev.PrepareAND(ca, cb);
+    ev.BlindRotateAssign(prep, nullptr, acc);
+    std::vector<uint32_t> tv(2 * op.N), want(2 * op.N);
+    orc_gate_testvec(&op, tv.data());
+    orc_blind_rotate(&op, fft, bsk.data(), prep.P.data(), tv.data(), -1, want.data());
+    EXPECT(std::equal(acc.A.begin(), acc.A.end(), want.begin()) && std::equal(acc.B.begin(), acc.B.end(), want.begin() + op.N), "BlindRotateAssign");
+    // error behaviour: a Go panic is a thrown Panic
+    bool threw = false;
+    try { gates::Ciphertext bad(3); gates::NAND(bad, bad, ck); } catch (const Panic &) { threw = true; }
+    EXPECT(threw, "wrong-length ciphertext must panic");
+    threw = false;
+    try { params::Params q = p; q.N = 512; cloudkey::CloudKey bad(q, nullptr, nullptr, 0); } catch (const Panic &e) { threw = e.code == TFHE_E_INVALID; }
+    EXPECT(threw, "unsupported parameter shape must panic");
+    orc_fft_free(fft);
+    std::printf(failures ? "host mirror: %d FAILURES\n" : "host mirror: all checks passed\n", failures);
+    return failures ? 1 : 0;
+}
