@@ -45,18 +45,25 @@ __device__ __forceinline__ void cfma(cd &acc, cd a, cd b)
 template <int S> __device__ __forceinline__ cd mul_i(cd a) { return S > 0 ? cd{-a.im, a.re} : cd{a.im, -a.re}; }
 
 // y_k = sum_n x_n exp(S * 2 pi i n k / 8), in place, natural order in and out.
+// 52 adds + 8 FMAs: the two 1/sqrt2 rotations of the odd half are not applied to d1, d3
+// themselves but folded into the FMAs that consume them (x1,x5 = f0 +- h*s, x3,x7 = f2 +- h*i*t).
 template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 {
     constexpr double h = 0.70710678118654752440;
     cd b0 = x[0] + x[4], b1 = x[1] + x[5], b2 = x[2] + x[6], b3 = x[3] + x[7];
     cd d0 = x[0] - x[4], t1 = x[1] - x[5], t2 = x[2] - x[6], t3 = x[3] - x[7];
-    cd d1 = S > 0 ? cd{(t1.re - t1.im) * h, (t1.im + t1.re) * h} : cd{(t1.re + t1.im) * h, (t1.im - t1.re) * h};
+    // u1 = t1 * (1 + S i), u3 = t3 * (-1 + S i)   (sqrt2 * the twiddled values)
+    cd u1 = S > 0 ? cd{t1.re - t1.im, t1.im + t1.re} : cd{t1.re + t1.im, t1.im - t1.re};
+    cd u3 = S > 0 ? cd{-t3.re - t3.im, t3.re - t3.im} : cd{t3.im - t3.re, -t3.im - t3.re};
     cd d2 = mul_i<S>(t2);
-    cd d3 = S > 0 ? cd{(-t3.re - t3.im) * h, (t3.re - t3.im) * h} : cd{(t3.im - t3.re) * h, (-t3.im - t3.re) * h};
     cd e0 = b0 + b2, e1 = b1 + b3, e2 = b0 - b2, e3 = mul_i<S>(b1 - b3);
     x[0] = e0 + e1; x[4] = e0 - e1; x[2] = e2 + e3; x[6] = e2 - e3;
-    cd f0 = d0 + d2, f1 = d1 + d3, f2 = d0 - d2, f3 = mul_i<S>(d1 - d3);
-    x[1] = f0 + f1; x[5] = f0 - f1; x[3] = f2 + f3; x[7] = f2 - f3;
+    cd f0 = d0 + d2, f2 = d0 - d2;
+    cd s = u1 + u3, t = mul_i<S>(u1 - u3);
+    x[1] = cd{fma(h, s.re, f0.re), fma(h, s.im, f0.im)};
+    x[5] = cd{fma(-h, s.re, f0.re), fma(-h, s.im, f0.im)};
+    x[3] = cd{fma(h, t.re, f2.re), fma(h, t.im, f2.im)};
+    x[7] = cd{fma(-h, t.re, f2.re), fma(-h, t.im, f2.im)};
 }
 
 // A wave's DS operations are executed in issue order, so a wave-private LDS exchange only
