@@ -26,7 +26,26 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
 BATCH = 1024
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/prof_pmc.sh (rocprofv3 --pmc passes)
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+    note in MI355X_MICROARCH.md, WRITE_SIZE as reported, both in KiB units), or None."""
+    try:
+        rec = json.load(open(PMC_FILE))[kernel]
+        return rec["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def fp64_flops_per_bootstrap(p):
+    """n x (2L+2 transforms x 5*(N/2)*log2(N/2) + 4L*(N/2)*8)."""
+    M = p.N // 2
+    logm = M.bit_length() - 1
+    return p.n * ((2 * p.L + 2) * 5 * M * logm + 4 * p.L * M * 8)
 
 
 def algorithmic_bytes_blind_rotate(p):
@@ -87,15 +106,28 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if os.environ.get("TFHE_BENCH_SHARE_GPU"):                    # dry run of the N>1 path on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU dry runs of the N>1 path
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
-    graft.build()
+    def barrier():
+        if dist:
+            dist.barrier()
+
+    # one rank compiles (no-op when the shipped .so is current), the others wait
+    if rank == 0:
+        graft.build()
+    barrier()
     pkg = graft.load_package()
     p = pkg.params.Security128Bit
 
@@ -123,23 +155,21 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     ctx.timing_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ctx.timing_enable(False)
     br_n, br_ms = ctx.timing_read(0)
     ks_n, ks_ms = ctx.timing_read(1)
     if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -160,8 +190,12 @@ def main():
                                    "128-bit params (n=700, N=1024, L=3, Bgbit=6, t=9), keys+inputs resident in HBM",
                        "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)"},
             "roofline": {"kernel": "k_blind_rotate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": br_avg_ms, "launches": br_n},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("k_blind_rotate"),
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": br_avg_ms, "launches": br_n,
+                         "note": "all 1024 workgroups stream the key in near lock-step, so it is served by L2/MALL: "
+                                 "algorithmic GB/s can exceed the HBM peak; the kernel is fp64-VALU/LDS bound",
+                         "fp64_tflops": fp64_flops_per_bootstrap(p) * BATCH / (br_avg_ms * 1e-3) / 1e12,
+                         "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
             "kernels": {"k_blind_rotate_ms": br_avg_ms, "k_extract_keyswitch_ms": ks_avg_ms,
                         "keyswitch_algorithmic_GBps": ks_alg / (ks_avg_ms * 1e-3) / 1e9 if ks_n else None},
         }
