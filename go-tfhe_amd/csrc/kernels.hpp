@@ -473,6 +473,105 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
 }
 
 // ------------------------------------------------------------------------------------
+// Tiled key switch for base = 4 (the 80/110/128-bit sets): a workgroup owns T ciphertexts and a
+// range of IC extracted coefficients.  For every (i, j) the three candidate key rows are fetched
+// from global memory ONCE (coalesced 16 B per lane, two steps ahead) and staged in a double-
+// buffered LDS tile next to an all-zero row; each of the T ciphertexts then subtracts the row its
+// (wave-uniform) digit selects with one ds_read_b128 at a scalar-computed offset -- no branches,
+// and the k = 0 case is the zero row.  Compared with the per-ciphertext gather this moves each
+// key row through L2/MALL once per T ciphertexts instead of once per ciphertext that needs it.
+// Partial sums of the N/IC coefficient ranges are combined with 32-bit atomic adds into `out`,
+// which k_ks_init has set to (0, ..., 0, b)  (keyswitch.go:18-21).
+// ------------------------------------------------------------------------------------
+__global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * (n + 1)) return;
+    const int b = (int)(idx / (n + 1)), x = (int)(idx % (n + 1));
+    out[idx] = x == n ? trlwe[(size_t)b * 2 * N + N] : 0u;
+}
+
+template <int T, int IC>
+__global__ __launch_bounds__(192) void k_keyswitch_tiled(KeySwitchArgs A, int B)
+{
+    constexpr int kRowQ = 192;                       // LDS row stride in uint4 (>= quads)
+    __shared__ uint4 rowbuf[2][4][kRowQ];            // [buffer][digit 0..3][quad]; digit 0 = zeros
+    __shared__ uint32_t wds[IC][T];
+    const int tid = threadIdx.x;
+    const int N = A.N, t = A.t, bb = A.basebit;      // base = 4 => bb = 2
+    const int b0 = blockIdx.x * T, i0 = blockIdx.y * IC;
+    const uint32_t prec = 1u << (32 - (1 + bb * t));
+    const int wshift = 32 - bb * t;
+    for (int idx = tid; idx < IC * T; idx += 192) {
+        const int ii = idx / T, b = idx - ii * T, i = i0 + ii;
+        uint32_t w = 0;
+        if (b0 + b < B) {
+            const uint32_t *ta = A.trlwe + (size_t)(b0 + b) * 2 * N;
+            const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];            // trlwe_ops.go:13-19
+            w = (ai + prec) >> wshift;                                     // all t digits, most significant first
+        }
+        wds[ii][b] = w;
+    }
+    rowbuf[0][0][tid] = make_uint4(0, 0, 0, 0);
+    rowbuf[1][0][tid] = make_uint4(0, 0, 0, 0);
+    const int quads = A.n1p >> 2;
+    const bool active = tid < quads;
+    const int qd = active ? tid : 0;
+    uint4 acc[T];
+#pragma unroll
+    for (int b = 0; b < T; b++) acc[b] = make_uint4(0, 0, 0, 0);
+    const uint4 *kbase = reinterpret_cast<const uint4 *>(A.ksk) + qd;
+    const size_t rowq = (size_t)quads;                                   // global row stride in uint4
+    const int F = IC * t;                                                // (i, j) pairs of this workgroup
+    const size_t f0 = (size_t)i0 * t;
+    auto row_ptr = [&](int f) { return kbase + ((f0 + f) * 3) * rowq; };
+    uint4 g1, g2, g3;                                                    // rows of pair f+1, in flight
+    {
+        const uint4 *rp = row_ptr(0);
+        rowbuf[0][1][tid] = rp[0]; rowbuf[0][2][tid] = rp[rowq]; rowbuf[0][3][tid] = rp[2 * rowq];
+        const uint4 *np = row_ptr(F > 1 ? 1 : 0);
+        g1 = np[0]; g2 = np[rowq]; g3 = np[2 * rowq];
+    }
+    __syncthreads();
+    uint32_t wd[T];
+    int j = 0, ii = 0;
+    for (int f = 0; f < F; f++) {
+        if (j == 0) {
+#pragma unroll
+            for (int b = 0; b < T; b++) wd[b] = __builtin_amdgcn_readfirstlane(wds[ii][b]);
+        }
+        const int cur = f & 1, nxt = cur ^ 1;
+        // stage pair f+1 (loaded one iteration ago) and start loading pair f+2
+        rowbuf[nxt][1][tid] = g1; rowbuf[nxt][2][tid] = g2; rowbuf[nxt][3][tid] = g3;
+        {
+            const uint4 *np = row_ptr(f + 2 < F ? f + 2 : F - 1);
+            g1 = np[0]; g2 = np[rowq]; g3 = np[2 * rowq];
+        }
+        const int sh = bb * (t - 1 - j);
+        const uint4 *tile = &rowbuf[cur][0][tid];
+#pragma unroll
+        for (int b = 0; b < T; b++) {
+            const uint32_t k = (wd[b] >> sh) & 3u;
+            const uint4 r = tile[k * kRowQ];
+            acc[b].x -= r.x; acc[b].y -= r.y; acc[b].z -= r.z; acc[b].w -= r.w;
+        }
+        __syncthreads();
+        if (++j == t) { j = 0; ii++; }
+    }
+    if (active) {
+#pragma unroll
+        for (int b = 0; b < T; b++) {
+            if (b0 + b >= B) break;
+            uint32_t *o = A.out + (size_t)(b0 + b) * (A.n + 1) + 4 * qd;
+            const uint32_t v[4] = {acc[b].x, acc[b].y, acc[b].z, acc[b].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (4 * qd + c <= A.n && v[c]) atomicAdd(o + c, v[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // FFT test seams, spectra in the reference FourierPoly layout.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_to_fourier(const uint32_t *__restrict__ polys, double *__restrict__ spectra,

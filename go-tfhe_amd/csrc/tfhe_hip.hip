@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -190,6 +191,17 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
+    // base-4 sets: tiled kernel (key rows shared by 32 ciphertexts); needs a full row in 192 lanes
+    constexpr int kT = 32, kIC = 32;
+    if (c->P.basebit == 2 && c->n1p <= 768 && c->P.N % kIC == 0 && B >= kT && !getenv("TFHE_KS_GATHER")) {
+        const size_t tot = (size_t)B * (c->P.n + 1);
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
+        hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((B + kT - 1) / kT, c->P.N / kIC), dim3(192), 0, st, a, B);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(stop, st));
+        c->ev_valid[1] = !c->timing;
+        return TFHE_OK;
+    }
     // row indices fit 16 bits for the 2-bit key-switch base of the N=1024 sets (halves the LDS list)
     const bool small_idx = ksk_rows_packed(c->P) < 65535;
 #define KS_LAUNCH(CH)                                                                                   \

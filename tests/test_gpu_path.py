@@ -90,6 +90,21 @@ def test_extract_keyswitch_bit_exact(oracle, request, which):
         assert np.array_equal(got[b], want), b
 
 
+@pytest.mark.parametrize("which,B", [("small", 70), ("128", 33), ("80", 64)])
+def test_extract_keyswitch_tiled_kernel_bit_exact(oracle, request, which, B):
+    # B >= 32 takes the tiled base-4 kernel (ragged last tile when B % 32 != 0)
+    k = request.getfixturevalue({"small": "keys_small", "80": "keys80", "128": "keys128"}[which])
+    ck = request.getfixturevalue({"small": "ck_small", "80": "ck80", "128": "ck128"}[which])
+    rs = np.random.RandomState(19)
+    trl = rand_u32(rs, (B, 2, 1024))
+    trl[3] = 0
+    trl[4] = 0xFFFFFFFF
+    got = ck.ctx.extract_keyswitch_batch(trl)
+    for b in range(B):
+        want = oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[b]))
+        assert np.array_equal(got[b], want), b
+
+
 def test_bootstrap_80bit_bit_exact_and_decrypts(oracle, keys80, ck80):
     k = keys80
     bits = [0, 1, 1]
