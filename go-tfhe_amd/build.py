@@ -6,17 +6,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(LIB_DIR, "libtfhe_hip.so")  # env override: kernel experiments
-SOURCES = ["tfhe_hip.hip"]
-HEADERS = ["kernels.hpp", "kernels_n2048.hpp", "negacyclic_fft.hpp", os.path.join("..", "..", "include", "tfhe_hip.h")]
+# (source, extra flags): the fp64 kernels get the max-ILP machine scheduler, the rest the default one
+SOURCES = [("tfhe_hip.hip", []), ("blind_rotate.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
+HEADERS = ["kernels.hpp", "kernels_n2048.hpp", "negacyclic_fft.hpp", "launch_blind_rotate.hpp", os.path.join("..", "..", "include", "tfhe_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in [x for x, _ in SOURCES] + HEADERS)
 
 
 def build(force=False, verbose=False):
@@ -24,8 +25,20 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    objs = []
+    procs = []
+    for src, extra in SOURCES:
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        cmd = [HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return LIB_PATH

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(128, 2) void k_external_product(const cd *bsk, cons
 // ------------------------------------------------------------------------------------
 
 // Reference Fourier layout [n][2L][2][N] float64 -> device layout.  One thread per complex.
-__global__ void k_bsk_from_fourier(const double *__restrict__ src, cd *__restrict__ dst, int n, int L)
+static __global__ void k_bsk_from_fourier(const double *__restrict__ src, cd *__restrict__ dst, int n, int L)
 {
     const size_t total = (size_t)n * 2 * L * 2 * 512;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,7 +362,7 @@ __global__ void k_bsk_from_fourier(const double *__restrict__ src, cd *__restric
 
 // Coefficient-domain key [n][2L][2][N] uint32 -> device layout (own forward FFT; replaces
 // trgsw.NewTRGSWLv1FFT, trgsw.go:71-82).  One wave per polynomial.
-__global__ __launch_bounds__(64) void k_bsk_from_torus(const uint32_t *__restrict__ src, cd *__restrict__ dst,
+static __global__ __launch_bounds__(64) void k_bsk_from_torus(const uint32_t *__restrict__ src, cd *__restrict__ dst,
                                                         const cd *__restrict__ twt, int L)
 {
     __shared__ cd sc[kScratchSlots];
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void k_bsk_from_torus(const uint32_t *__restric
 
 // Reference KSK [N*t*base][n+1] -> packed [N*t*(base-1) + 1][n1p] (drops the all-zero k = 0 rows;
 // ONE all-zero row is kept at the end as padding target for the unrolled gather).
-__global__ void k_ksk_pack(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n1, int n1p,
+static __global__ void k_ksk_pack(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int n1, int n1p,
                            int base, size_t rows_packed)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
 // Partial sums of the N/IC coefficient ranges are combined with 32-bit atomic adds into `out`,
 // which k_ks_init has set to (0, ..., 0, b)  (keyswitch.go:18-21).
 // ------------------------------------------------------------------------------------
-__global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B)
+static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * (n + 1)) return;
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(192) void k_keyswitch_tiled(KeySwitchArgs A, int B)
 // ------------------------------------------------------------------------------------
 // FFT test seams, spectra in the reference FourierPoly layout.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_to_fourier(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
+static __global__ __launch_bounds__(64) void k_to_fourier(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
                                                     const cd *__restrict__ twt)
 {
     __shared__ cd sc[kScratchSlots];
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void k_to_fourier(const uint32_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(64) void k_to_poly(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
+static __global__ __launch_bounds__(64) void k_to_poly(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
                                                  const cd *__restrict__ twt)
 {
     __shared__ cd sc[kScratchSlots];
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void k_to_poly(const double *__restrict__ spect
 }
 
 // Small helpers for the MUX composition (gates.go:107-114): gather / scatter LWE samples.
-__global__ void k_gather_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
+static __global__ void k_gather_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
                               int n1, int count)
 {
     const int r = blockIdx.x;
@@ -628,7 +628,7 @@ __global__ void k_gather_rows(const uint32_t *__restrict__ src, const int *__res
     for (int x = threadIdx.x; x < n1; x += blockDim.x) dst[(size_t)r * n1 + x] = src[(size_t)idx[r] * n1 + x];
 }
 
-__global__ void k_scatter_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
+static __global__ void k_scatter_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
                                int n1, int count)
 {
     const int r = blockIdx.x;

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(128) void k_external_product_2048(const cd *bsk, co
 }
 
 // Reference Fourier layout [n][2][2][2048] float64 -> device layout (L = 1).
-__global__ void k_bsk_from_fourier_2048(const double *__restrict__ src, cd *__restrict__ dst, int n)
+static __global__ void k_bsk_from_fourier_2048(const double *__restrict__ src, cd *__restrict__ dst, int n)
 {
     const size_t total = (size_t)n * 2 * 2 * 1024;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,7 +230,7 @@ __global__ void k_bsk_from_fourier_2048(const double *__restrict__ src, cd *__re
     dst[idx] = cd{poly[base], poly[base + 4]};
 }
 
-__global__ __launch_bounds__(64) void k_bsk_from_torus_2048(const uint32_t *__restrict__ src, cd *__restrict__ dst,
+static __global__ __launch_bounds__(64) void k_bsk_from_torus_2048(const uint32_t *__restrict__ src, cd *__restrict__ dst,
                                                              const cd *__restrict__ twt)
 {
     __shared__ cd sc[kScratchSlots];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_bsk_from_torus_2048(const uint32_t *__re
     for (int k = 0; k < 16; k++) dst[((size_t)polyIdx * 16 + k) * 64 + lane] = x[k];
 }
 
-__global__ __launch_bounds__(64) void k_to_fourier_2048(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
+static __global__ __launch_bounds__(64) void k_to_fourier_2048(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
                                                          const cd *__restrict__ twt)
 {
     __shared__ cd sc[kScratchSlots];
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(64) void k_to_fourier_2048(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(64) void k_to_poly_2048(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
+static __global__ __launch_bounds__(64) void k_to_poly_2048(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
                                                       const cd *__restrict__ twt)
 {
     __shared__ cd sc[kScratchSlots];

@@ -74,6 +74,15 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 #define TFHE_XCHG(stmt) stmt
 #endif
 
+#ifndef TFHE_NO_XCHG_PRIO
+// waves issuing an LDS exchange run at raised priority so the exchange gets into the (CU-shared)
+// LDS pipe early and its latency overlaps the other waves' fp64 work (-4 % blind-rotate time when applied to the batched forward exchanges; the same on the
+// inverse / partner exchanges measured +3 %, so only the forward path uses it)
+#define TFHE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define TFHE_PRIO(n)
+#endif
+
 __device__ __forceinline__ void wave_lds_order()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -194,23 +203,27 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
 #pragma unroll
         for (int a = 1; a < 8; a++) x[t][a] = cmul(x[t][a], table[a]);
         dft8<1>(x[t]);
+        TFHE_PRIO(3);
 #pragma unroll
         TFHE_XCHG(for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];)
         wave_lds_order();
 #pragma unroll
         TFHE_XCHG(for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];)
         wave_lds_order();
+        TFHE_PRIO(0);
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
         twist_pow<false>(x[t], tw.l2);
         dft8<1>(x[t]);
+        TFHE_PRIO(3);
 #pragma unroll
         TFHE_XCHG(for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];)
         wave_lds_order();
 #pragma unroll
         TFHE_XCHG(for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];)
         wave_lds_order();
+        TFHE_PRIO(0);
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {

@@ -18,6 +18,7 @@
 
 #include "kernels.hpp"
 #include "kernels_n2048.hpp"
+#include "launch_blind_rotate.hpp"
 
 using namespace tfhe;
 
@@ -170,10 +171,7 @@ int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in
     hipEvent_t stop;
     int trc = timing_begin(c, 0, st, &stop);
     if (trc) return trc;
-    if (c->shape == 1)
-        hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(128), 0, st, a);
+    launch_blind_rotate(c->shape, a, B, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(stop, st));
     c->ev_valid[0] = !c->timing;
@@ -196,7 +194,12 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     if (c->P.basebit == 2 && c->n1p <= 768 && c->P.N % kIC == 0 && B >= kT && !getenv("TFHE_KS_GATHER")) {
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
-        hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((B + kT - 1) / kT, c->P.N / kIC), dim3(192), 0, st, a, B);
+        const char *icv = getenv("TFHE_KS_IC");
+        const int ic = icv ? atoi(icv) : kIC;
+        if (ic == 64) hipLaunchKernelGGL((k_keyswitch_tiled<kT, 64>), dim3((B + kT - 1) / kT, c->P.N / 64), dim3(192), 0, st, a, B);
+        else if (ic == 128) hipLaunchKernelGGL((k_keyswitch_tiled<kT, 128>), dim3((B + kT - 1) / kT, c->P.N / 128), dim3(192), 0, st, a, B);
+        else if (ic == 16) hipLaunchKernelGGL((k_keyswitch_tiled<kT, 16>), dim3((B + kT - 1) / kT, c->P.N / 16), dim3(192), 0, st, a, B);
+        else hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((B + kT - 1) / kT, c->P.N / kIC), dim3(192), 0, st, a, B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(stop, st));
         c->ev_valid[1] = !c->timing;
@@ -573,12 +576,8 @@ int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, 
     const size_t trl = (size_t)B * 2 * c->P.N * 4;
     if ((rc = c->s_trlwe.reserve(trl)) || (rc = c->s_t0.reserve(trl))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
-    if (c->shape == 1)
-        hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, c->stream, c->bsk.as<cd>(), c->tw.as<cd>(),
-                           key_index, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->offset);
-    else
-        hipLaunchKernelGGL((k_external_product_2048<22>), dim3(B), dim3(128), 0, c->stream, c->bsk.as<cd>(),
-                           c->tw.as<cd>(), key_index, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->offset);
+    launch_external_product(c->shape, c->bsk.as<cd>(), c->tw.as<cd>(), key_index, c->s_trlwe.as<uint32_t>(),
+                            c->s_t0.as<uint32_t>(), c->offset, B, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->s_t0.p, trl, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
