@@ -63,8 +63,56 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
         y0[a] = x[a] + rv;                                           // mod X^512 - rho
         y1[a] = x[a] - rv;                                           // mod X^512 + rho
     }
-    fft512_forward(y0, sc, table, tw.h[0], lane);
-    fft512_forward(y1, sc, table + kTwCount1024, tw.h[1], lane);
+    // the two halves advance level by level through the one scratch buffer (same in-order DS
+    // argument as fft512_forward_batch), each with its own twiddle tables
+    {
+        const int hi = lane >> 3, lo = lane & 7;
+        const cd *t0 = table, *t1 = table + kTwCount1024;
+#pragma unroll
+        for (int a = 1; a < 8; a++) { y0[a] = cmul(y0[a], t0[a]); y1[a] = cmul(y1[a], t1[a]); }
+        dft8<1>(y0);
+        TFHE_PRIO(3);
+#pragma unroll
+        for (int m = 0; m < 8; m++) sc[72 * m + lane] = y0[m];
+        wave_lds_order();
+#pragma unroll
+        for (int b = 0; b < 8; b++) y0[b] = sc[72 * hi + 8 * b + lo];
+        wave_lds_order();
+        TFHE_PRIO(0);
+        dft8<1>(y1);
+        TFHE_PRIO(3);
+#pragma unroll
+        for (int m = 0; m < 8; m++) sc[72 * m + lane] = y1[m];
+        wave_lds_order();
+#pragma unroll
+        for (int b = 0; b < 8; b++) y1[b] = sc[72 * hi + 8 * b + lo];
+        wave_lds_order();
+        TFHE_PRIO(0);
+        twist_pow<false>(y0, tw.h[0].l2);
+        dft8<1>(y0);
+        TFHE_PRIO(3);
+#pragma unroll
+        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = y0[mp];
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < 8; c++) y0[c] = sc[72 * hi + 9 * lo + c];
+        wave_lds_order();
+        TFHE_PRIO(0);
+        twist_pow<false>(y1, tw.h[1].l2);
+        dft8<1>(y1);
+        TFHE_PRIO(3);
+#pragma unroll
+        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = y1[mp];
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < 8; c++) y1[c] = sc[72 * hi + 9 * lo + c];
+        wave_lds_order();
+        TFHE_PRIO(0);
+        twist_pow<false>(y0, tw.h[0].l3);
+        dft8<1>(y0);
+        twist_pow<false>(y1, tw.h[1].l3);
+        dft8<1>(y1);
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) { x[k] = y0[k]; x[8 + k] = y1[k]; }
 }
