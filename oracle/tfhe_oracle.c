@@ -58,6 +58,10 @@ uint32_t orc_decomposition_offset(const orc_params *p)
 
 struct orc_fft {
     int N, M;           /* ring degree, M = N/2 complex points */
+    /* per-evaluator scratch (the reference's evaluator is buffer-pooled / "zero-allocation",
+     * evaluator/buffers.go:21-73; one orc_fft per thread plays that role) */
+    uint32_t *w_dig, *w_diff, *w_prod;   /* 8N, 2N, 2N words */
+    double *w_spec, *w_sa, *w_sb;        /* N doubles each   */
     double *tw_re, *tw_im;     /* forward twiddles, M-1 entries (poly_evaluator.go:114-133) */
     double *twi_re, *twi_im;   /* inverse twiddles, M-1 entries (:135-140) */
 };
@@ -119,13 +123,21 @@ orc_fft *orc_fft_new(int N)
         }
     }
     free(br); free(bi); free(cr); free(ci);
+    f->w_dig = (uint32_t *)malloc(sizeof(uint32_t) * 8 * N);
+    f->w_diff = (uint32_t *)malloc(sizeof(uint32_t) * 2 * N);
+    f->w_prod = (uint32_t *)malloc(sizeof(uint32_t) * 2 * N);
+    f->w_spec = (double *)malloc(sizeof(double) * N);
+    f->w_sa = (double *)malloc(sizeof(double) * N);
+    f->w_sb = (double *)malloc(sizeof(double) * N);
     return f;
 }
 
 void orc_fft_free(orc_fft *f)
 {
     if (!f) return;
-    free(f->tw_re); free(f->tw_im); free(f->twi_re); free(f->twi_im); free(f);
+    free(f->tw_re); free(f->tw_im); free(f->twi_re); free(f->twi_im);
+    free(f->w_dig); free(f->w_diff); free(f->w_prod); free(f->w_spec); free(f->w_sa); free(f->w_sb);
+    free(f);
 }
 
 /* FourierPoly storage (poly/poly.go:54-62): complex slot c lives at doubles
@@ -263,9 +275,10 @@ void orc_external_product(const orc_params *p, const orc_fft *f, const double *b
 {
     int N = p->N, L = p->L;
     uint32_t off = orc_decomposition_offset(p);
-    uint32_t *dig = (uint32_t *)malloc(sizeof(uint32_t) * 2 * L * N);
-    double *spec = (double *)malloc(sizeof(double) * N);
-    double *sa = (double *)calloc(N, sizeof(double)), *sb = (double *)calloc(N, sizeof(double));
+    uint32_t *dig = f->w_dig;                       /* 2L*N <= 8N words */
+    double *spec = f->w_spec, *sa = f->w_sa, *sb = f->w_sb;
+    memset(sa, 0, sizeof(double) * N);              /* FourierA/B.Clear() (evaluator.go:69-70) */
+    memset(sb, 0, sizeof(double) * N);
     orc_decompose(p, in, off, dig);                 /* A digits -> rows 0..L-1   (:59) */
     orc_decompose(p, in + N, off, dig + L * N);     /* B digits -> rows L..2L-1  (:61) */
     for (int r = 0; r < 2 * L; r++) {               /* same accumulation order as :73-76 */
@@ -275,7 +288,6 @@ void orc_external_product(const orc_params *p, const orc_fft *f, const double *b
     }
     orc_to_poly(f, sa, out, NULL);
     orc_to_poly(f, sb, out + N, NULL);
-    free(dig); free(spec); free(sa); free(sb);
 }
 
 void orc_external_product_exact(const orc_params *p, const uint32_t *bsk_i, const uint32_t *in,
@@ -301,12 +313,10 @@ void orc_cmux(const orc_params *p, const orc_fft *f, const double *bsk_i, const 
               const uint32_t *ct1, uint32_t *out)
 {
     int N2 = 2 * p->N;
-    uint32_t *diff = (uint32_t *)calloc(N2, sizeof(uint32_t));
-    uint32_t *prod = (uint32_t *)malloc(sizeof(uint32_t) * N2);
+    uint32_t *diff = f->w_diff, *prod = f->w_prod;
     for (int j = 0; j < N2; j++) diff[j] = ct1[j] - ct0[j];
     orc_external_product(p, f, bsk_i, diff, prod);
     for (int j = 0; j < N2; j++) out[j] = ct0[j] + prod[j];
-    free(diff); free(prod);
 }
 
 /* Mod-switch of the body and of a mask word (evaluator.go:116,122). */
