@@ -56,6 +56,7 @@ def load_library():
         "tfhe_load_bsk_fourier": [vp, f64p],
         "tfhe_load_bsk_torus": [vp, u32p],
         "tfhe_load_ksk": [vp, u32p],
+        "tfhe_keygen_cloud": [vp, u32p, u32p, C.c_double, C.c_double, C.c_uint64],
         "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
         "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "tfhe_blind_rotate_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int, C.c_int],
@@ -148,6 +149,13 @@ class Context:
         p = self.params
         ksk = _u32(ksk, (p.ksk_rows, p.n + 1))
         self._check(self._lib.tfhe_load_ksk(self._h, _p32(ksk)))
+
+    def keygen_cloud(self, s0, s1, alpha_lv0, alpha_lv1, seed):
+        """cloudkey.NewCloudKey on the GPU from the binary secret keys (no key upload)."""
+        p = self.params
+        s0, s1 = _u32(s0, (p.n,)), _u32(s1, (p.N,))
+        self._check(self._lib.tfhe_keygen_cloud(self._h, _p32(s0), _p32(s1), float(alpha_lv0), float(alpha_lv1),
+                                                C.c_uint64(int(seed))))
 
     # ---- host-pointer entry points
     def _tv(self, tv, B):

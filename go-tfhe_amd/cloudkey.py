@@ -22,3 +22,11 @@ class CloudKey:
 
     def close(self):
         self.ctx.close()
+
+    @classmethod
+    def NewCloudKey(cls, params, key_lv0, key_lv1, alpha_lv0, alpha_lv1, seed=0, device=0):
+        """cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31) generated ON the GPU
+        (tfhe_keygen_cloud): nothing but the two binary secret keys crosses PCIe."""
+        ck = cls(params, device=device)
+        ck.ctx.keygen_cloud(key_lv0, key_lv1, alpha_lv0, alpha_lv1, seed)
+        return ck

@@ -19,6 +19,7 @@
 #include "kernels.hpp"
 #include "kernels_n2048.hpp"
 #include "launch_blind_rotate.hpp"
+#include "keygen.hpp"
 
 using namespace tfhe;
 
@@ -430,6 +431,47 @@ int tfhe_load_ksk(tfhe_ctx *c, const uint32_t *ksk)
     HIP_TRY(hipStreamSynchronize(c->stream));
     raw.release();
     c->have_ksk = true;
+    return TFHE_OK;
+}
+
+int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
+                      uint64_t seed)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!s0 || !s1) return fail(TFHE_E_INVALID, "null secret key");
+    if (!(alpha_lv0 >= 0.0) || !(alpha_lv1 >= 0.0) || alpha_lv0 >= 0.25 || alpha_lv1 >= 0.25)
+        return fail(TFHE_E_INVALID, "noise parameters out of range");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const tfhe_params &P = c->P;
+    for (int i = 0; i < P.n; i++) if (s0[i] > 1) return fail(TFHE_E_INVALID, "level-0 key is not binary at %d", i);
+    for (int i = 0; i < P.N; i++) if (s1[i] > 1) return fail(TFHE_E_INVALID, "level-1 key is not binary at %d", i);
+    DevBuf d_s0, d_s1, d_spec;
+    const size_t rows_p = ksk_rows_packed(P) + 1;
+    if ((rc = d_s0.reserve((size_t)P.n * 4)) || (rc = d_s1.reserve((size_t)P.N * 4)) ||
+        (rc = d_spec.reserve((size_t)(P.N / 2) * sizeof(cd))) || (rc = c->bsk.reserve(bsk_elems(P) * sizeof(cd))) ||
+        (rc = c->ksk.reserve(rows_p * c->n1p * sizeof(uint32_t)))) {
+        d_s0.release(); d_s1.release(); d_spec.release();
+        return rc;
+    }
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemcpyAsync(d_s0.p, s0, (size_t)P.n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_s1.p, s1, (size_t)P.N * 4, hipMemcpyHostToDevice, st));
+    if (c->shape == 1) {
+        hipLaunchKernelGGL(k_keygen_s1_spectrum, dim3(1), dim3(64), 0, st, d_s1.as<uint32_t>(), d_spec.as<cd>(), c->tw.as<cd>());
+        hipLaunchKernelGGL((k_keygen_bsk<3, 6>), dim3(P.n * 2 * P.L), dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(),
+                           d_spec.as<cd>(), d_s0.as<uint32_t>(), alpha_lv1, seed);
+    } else {
+        hipLaunchKernelGGL(k_keygen_s1_spectrum_2048, dim3(1), dim3(64), 0, st, d_s1.as<uint32_t>(), d_spec.as<cd>(), c->tw.as<cd>());
+        hipLaunchKernelGGL((k_keygen_bsk_2048<22>), dim3(P.n * 2), dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(),
+                           d_spec.as<cd>(), d_s0.as<uint32_t>(), alpha_lv1, seed);
+    }
+    hipLaunchKernelGGL(k_keygen_ksk, dim3((unsigned)rows_p), dim3(64), 0, st, c->ksk.as<uint32_t>(), d_s0.as<uint32_t>(),
+                       d_s1.as<uint32_t>(), P.n, c->n1p, P.t, P.basebit, rows_p, alpha_lv0, seed ^ 0x9E3779B97F4A7C15ull);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    d_s0.release(); d_s1.release(); d_spec.release();
+    c->have_bsk = c->have_ksk = true;
     return TFHE_OK;
 }
 

@@ -92,6 +92,16 @@ class CloudKey {
         check(tfhe_load_bsk_torus(ck->ctx_, bsk_torus));
         return ck;
     }
+    // cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31), generated on the GPU
+    static std::unique_ptr<CloudKey> NewCloudKey(const params::Params &p, const std::vector<uint32_t> &keyLv0,
+                                                 const std::vector<uint32_t> &keyLv1, double alphaLv0, double alphaLv1,
+                                                 uint64_t seed, int device = 0)
+    {
+        auto ck = std::make_unique<CloudKey>(p, nullptr, nullptr, device);
+        if ((int)keyLv0.size() != p.n || (int)keyLv1.size() != p.N) throw Panic(TFHE_E_INVALID, "secret key has the wrong length");
+        check(tfhe_keygen_cloud(ck->ctx_, keyLv0.data(), keyLv1.data(), alphaLv0, alphaLv1, seed));
+        return ck;
+    }
     ~CloudKey() { if (ctx_) tfhe_ctx_destroy(ctx_); }
     CloudKey(const CloudKey &) = delete;
     CloudKey &operator=(const CloudKey &) = delete;

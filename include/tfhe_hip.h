@@ -88,6 +88,16 @@ int tfhe_load_bsk_torus(tfhe_ctx *ctx, const uint32_t *bsk);
  * base*t*i + base*j + k (keyswitch.go:29). */
 int tfhe_load_ksk(tfhe_ctx *ctx, const uint32_t *ksk);
 
+/* cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31) on the GPU: genBootstrappingKey
+ * (cloudkey.go:123-145, trgsw.go:32-82) and genKeySwitchingKey (cloudkey.go:88-120) written
+ * straight into the engine's device layouts -- no host-side key, no upload.
+ *   s0 [n], s1 [N]: the binary secret keys (key.SecretKey.KeyLv0 / KeyLv1, key.go:10-13)
+ *   alpha_lv0 = params.KSKAlpha(), alpha_lv1 = params.BSKAlpha()   (params.go:629-636)
+ *   seed: the reference is unseeded (math/rand auto-seed); here the same (seed, key) pair always
+ *         gives the same cloud key (counter-based Philox streams). */
+int tfhe_keygen_cloud(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *s1, double alpha_lv0,
+                      double alpha_lv1, uint64_t seed);
+
 /* Evaluator.BootstrapAssign / BootstrapLUTAssign over a batch (evaluator.go:139-148,
  * programmable_bootstrap.go:93-115; batch fan-out trgsw.go:234-252).
  *   in      [B][n+1]

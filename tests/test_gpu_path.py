@@ -197,3 +197,17 @@ def test_edge_cases_and_errors(pkg, keys_small, ck_small):
         ck_small.ctx.gate_batch("MUX", np.zeros((1, n1), np.uint32), np.zeros((1, n1), np.uint32))
     with pytest.raises(pkg.TfheError):                      # bad op code
         ck_small.ctx.gate_batch(np.array([77], np.uint8), np.zeros((1, n1), np.uint32), np.zeros((1, n1), np.uint32))
+
+
+def test_110bit_parameter_set(oracle, pkg):
+    # params.go:117-146 (n=630, t=8): same kernels, different LWE dimension / key-switch depth
+    from conftest import KeySet, gpu_params
+    k = KeySet(oracle, "110", 0x7F4E0006, torus=False)
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    A, B = [0, 0, 1, 1] * 9, [0, 1, 0, 1] * 9                 # 36 items: tiled key switch + ragged tile
+    a, b = k.enc(A), k.enc(B)
+    for op in ("NAND", "XOR"):
+        out = ck.ctx.gate_batch(op, a, b)
+        assert list(k.dec(out)) == [bool(TRUTH[op](bool(x), bool(y))) for x, y in zip(A, B)]
+        assert np.array_equal(out[33], oracle.gate(k.p, k.bsk, k.ksk, op, a[33], b[33]))
+    ck.close()
