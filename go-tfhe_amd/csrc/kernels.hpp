@@ -248,6 +248,9 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BlindRotateArgs A)
     __shared__ uint32_t accL[2][N];
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
+#ifdef TFHE_TW_LDS   // experiment: measured +3 % slower (spills, extra LDS reads) than rebuilding the powers
+    __shared__ cd twL[2 * 4 * 64];
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,6 +278,10 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BlindRotateArgs A)
     }
     LaneTwiddles tw;
     load_lane_twiddles(tw, A.tw, lane);
+#ifdef TFHE_TW_LDS   // experiment: measured +3 % slower (spills, extra LDS reads) than rebuilding the powers
+    fill_twiddle_lds(twL, A.tw, tid, 128);
+    use_twiddle_lds(tw, twL, lane);
+#endif
     __syncthreads();
 
     // ---- acc = X^bt * testvec  (evaluator.go:117-118, buffer_methods.go:133-164)
