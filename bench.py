@@ -61,6 +61,25 @@ def algorithmic_bytes_keyswitch(p):
     return rows * (p.n + 1) * 4 + 2 * p.N * 4 + (p.n + 1) * 4
 
 
+def effective_cores():
+    """Host cores this process may actually use: affinity mask, capped by the cgroup CPU quota
+    (the GPU box exposes 256 logical CPUs but a 16-CPU quota; oversubscribing it collapses)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(p128, a, b, bsk_torus, ksk, budget_s=12.0):
     """Oracle (port of the reference) on the host cores: all threads, one bootstrap per thread
     (mirrors trgsw.BatchBlindRotate's goroutine per input, trgsw.go:234-252)."""
@@ -73,7 +92,7 @@ def cpu_baseline(p128, a, b, bsk_torus, ksk, budget_s=12.0):
     flat_f = bsk_f.reshape(-1, p.N)
     for i in range(flat_t.shape[0]):
         flat_f[i] = o.to_fourier(flat_t[i])
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     # single-thread latency on 2 gates (comparable to BenchmarkBootstrapNAND, gates_test.go:505-518)
     t0 = time.perf_counter()
     o.gate_batch(p, bsk_f, ksk, "NAND", a[:2], b[:2], nthreads=1)
