@@ -11,7 +11,7 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a, int B, hipStream_t
     if (shape == 1)
         hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a);
     else
-        hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(128), 0, st, a);
+        hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(256), 0, st, a);
 }
 
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,

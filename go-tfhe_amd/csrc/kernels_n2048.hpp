@@ -184,16 +184,26 @@ __device__ __forceinline__ void external_product_core_2048(const uint32_t *accL,
     }
 }
 
+// Blind rotate for N = 2048 with FOUR waves per bootstrap: wave (p, h) owns half h of the root tree
+// (X^512 = +-rho) of accumulator polynomial p.  A batch of 512 PBS puts 2 workgroups on each CU, so
+// four waves per workgroup give every SIMD two waves (fp64 issue ~5.5 instead of ~8 cycles/instr).
+// Per step and wave: rebuild the 16 digit points of its polynomial, fold them to its half
+// (y = x_lo +- rho*x_hi), one 512-point forward transform, multiply with its 8+8 key slices, swap
+// the partner polynomial's share with wave (1-p, h), one 512-point inverse transform, then swap
+// halves with wave (p, 1-h) to undo the radix-2 level; wave h writes coefficient block
+// [512h, 512h+512) + {0, 1024}.  Four s_barriers per step.
 template <int BGBIT>
-__global__ __launch_bounds__(128) void k_blind_rotate_2048(BlindRotateArgs A)
+__global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
 {
     constexpr int N = 2048;
-    __shared__ cd sc[2][kScratchSlots2048];
+    constexpr double r = 0.70710678118654752440;
+    __shared__ cd sc[4][kScratchSlots];
     __shared__ uint32_t accL[2][N];
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = w >> 1, h = w & 1;
     const int item = blockIdx.x;
     const int n = A.n;
     {
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(128) void k_blind_rotate_2048(BlindRotateArgs A)
         const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
         const int sh = 32 - A.Nbit - 1;
         const uint32_t rnd = 1u << (sh - 1);
-        for (int x = tid; x <= n; x += 128) {
+        for (int x = tid; x <= n; x += 256) {
             uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
             if (x == n) {
                 v += g.cst;
@@ -213,36 +223,83 @@ __global__ __launch_bounds__(128) void k_blind_rotate_2048(BlindRotateArgs A)
             }
         }
     }
-    LaneTwiddles2048 tw;
-    load_lane_twiddles_2048(tw, A.tw, lane);
+    LaneTwiddles tw;
+    const cd *table = A.tw + (size_t)h * kTwCount1024;
+    load_lane_twiddles(tw, table, lane);
     __syncthreads();
     {
         const int bt = btL & (2 * N - 1);
         const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
 #pragma unroll
-        for (int q = 0; q < 32; q++) {
-            const int j = 64 * q + lane;
+        for (int q = 0; q < 16; q++) {                 // wave h initialises its coefficient block
+            const int j = (q < 8 ? 64 * q + lane : 64 * (q - 8) + lane + 1024) + 512 * h;
             const int s = (j - bt) & (2 * N - 1);
             uint32_t v = tv[s & (N - 1)];
             v ^= 0u - (uint32_t)((s >> 11) & 1);
             accL[p][j] = v;
         }
     }
-    wave_lds_order();
-    const cd *key = A.bsk + (size_t)p * 2 * 1024;
+    __syncthreads();
+    constexpr uint32_t mask = (1u << BGBIT) - 1u;
+    constexpr int half = 1 << (BGBIT - 1);
+    constexpr int shift = 32 - BGBIT;
+    const cd *key = A.bsk + (size_t)p * 2 * 1024 + (size_t)h * 8 * 64 + lane;
     constexpr size_t kStep = (size_t)2 * 2 * 1024;
+    const int wpart = ((1 - p) << 1) | h;               // same half of the other polynomial
     for (int i = 0; i < A.nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
-        uint32_t e[32];
-        external_product_core_2048<BGBIT>(accL[p], at, nullptr, e, key + (size_t)i * kStep, sc[p], sc[p ^ 1], A.tw, tw,
-                                          A.offset, p, lane);
+        const cd *kp = key + (size_t)i * kStep;
+        cd y[8];
 #pragma unroll
-        for (int q = 0; q < 32; q++) accL[p][64 * q + lane] += e[q];
-        wave_lds_order();
+        for (int a = 0; a < 8; a++) {
+            const uint32_t d0 = diff_coeff_2048(accL[p], at, nullptr, 64 * a + lane) + A.offset;
+            const uint32_t d1 = diff_coeff_2048(accL[p], at, nullptr, 64 * a + lane + 1024) + A.offset;
+            const uint32_t d2 = diff_coeff_2048(accL[p], at, nullptr, 64 * (a + 8) + lane) + A.offset;
+            const uint32_t d3 = diff_coeff_2048(accL[p], at, nullptr, 64 * (a + 8) + lane + 1024) + A.offset;
+            const cd lo = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
+            const cd hi = cd{(double)((int)((d2 >> shift) & mask) - half), (double)((int)((d3 >> shift) & mask) - half)};
+            const cd rv = cd{(hi.re - hi.im) * r, (hi.re + hi.im) * r};          // rho * hi
+            y[a] = h ? lo - rv : lo + rv;
+        }
+        fft512_forward(y, sc[w], table, tw, lane);
+        const cd *kKeep = kp + (size_t)(p ? 1 : 0) * 1024;
+        const cd *kSend = kp + (size_t)(p ? 0 : 1) * 1024;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            sc[w][k * 64 + lane] = cmul(y[k], kSend[k * 64]);
+            y[k] = cmul(y[k], kKeep[k * 64]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; k++) y[k] = y[k] + sc[wpart][k * 64 + lane];
+        __syncthreads();
+        fft512_inverse(y, sc[w], table, tw, lane);      // table carries conj(c1)/1024
+#pragma unroll
+        for (int k = 0; k < 8; k++) sc[w][k * 64 + lane] = y[k];
+        __syncthreads();
+        uint32_t e[16];
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            const cd o = sc[w ^ 1][a * 64 + lane];
+            cd x;
+            if (h == 0) x = y[a] + o;                                            // x[a]   = y0 + y1
+            else { const cd dl = o - y[a]; x = cd{(dl.re + dl.im) * r, (dl.im - dl.re) * r}; }   // x[a+8] = conj(rho)(y0 - y1)
+            e[a] = round_to_torus_wide(x.re);
+            e[a + 8] = round_to_torus_wide(x.im);
+        }
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            accL[p][64 * a + lane + 512 * h] += e[a];
+            accL[p][64 * a + lane + 512 * h + 1024] += e[a + 8];
+        }
+        __syncthreads();
     }
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
-    for (int q = 0; q < 32; q++) out[64 * q + lane] = accL[p][64 * q + lane];
+    for (int q = 0; q < 16; q++) {
+        const int j = (q < 8 ? 64 * q + lane : 64 * (q - 8) + lane + 1024) + 512 * h;
+        out[j] = accL[p][j];
+    }
 }
 
 template <int BGBIT>
