@@ -4,8 +4,8 @@
 //                         linear preparation (gates_helper.go:10-63) and the mod-switch fused
 //                         into its prologue.  One workgroup = one bootstrap, two wavefronts:
 //                         wave 0 owns accumulator polynomial A, wave 1 owns B.  The n CMUX
-//                         steps run inside the kernel with the accumulator resident in
-//                         registers + LDS; only the bootstrapping key is streamed.
+//                         steps run inside the kernel with the accumulator resident in LDS;
+//                         only the bootstrapping key is streamed.
 //   k_external_product    evaluator.ExternalProductAssign (evaluator.go:50-81), same core.
 //   k_extract_keyswitch   trlwe.SampleExtractIndexAssign + trgsw.IdentityKeySwitchingAssign
 //                         (trlwe_ops.go:10-21, keyswitch.go:10-37).
@@ -80,12 +80,6 @@ struct BlindRotateArgs {
 
 constexpr int kMaxLweDim = 1088;
 
-// One CMUX "core": given the difference polynomial d (this wave's half, 16 coefficients per
-// lane: q < 8 -> j = 64q+lane, q >= 8 -> j = 64(q-8)+lane+512), produce this wave's half of
-// bsk[i] (x) d as 16 torus words.  Two waves cooperate: each transforms the L digit
-// polynomials of its own half, multiplies them with its L key rows into partial sums for
-// BOTH outputs, hands the partner's partial sum over through LDS, and inverse-transforms
-// its own.  (evaluator.go:50-81; decomposer.go:55-66; fourier_ops.go:167-191)
 // Key slices of one gadget level for one wave: 8 register-slices of the spectrum it keeps and
 // 8 of the spectrum it hands to its partner (64 VGPRs), fetched one level ahead of use so the
 // L2/MALL latency hides under the forward FFT in between.
@@ -100,11 +94,6 @@ __device__ __forceinline__ void load_keys(KeyRegs &K, const cd *__restrict__ key
     // wave p keeps output p: p = 0 accumulates the A output from part 0, p = 1 the B output
     const cd *kKeep = p ? kB : kA;
     const cd *kSend = p ? kA : kB;
-#ifdef ABLATE_KEYLOAD
-    // same addresses every step: stays L1/L2 hot (timing experiment only, wrong results)
-    kKeep = (const cd *)((uintptr_t)kKeep & 0xFFFFFFFFFFFF0000ull) + lane;
-    kSend = kKeep + 512;
-#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         K.keep[k] = kKeep[k * 64];
@@ -131,6 +120,12 @@ __device__ __forceinline__ uint32_t diff_coeff(const DiffSource &S, int j)
     return v - S.accL[j];                          // d = X^at*acc - acc (evaluator.go:93-96,122-126)
 }
 
+// One external product, this wave's half: from the polynomial S describes (16 coefficients per
+// lane: j = 64a+lane and j+512, a < 8) produce this wave's half of bsk[i] (x) d as 16 torus words.
+// Two waves cooperate: each transforms the L digit polynomials of its own polynomial, multiplies
+// them with its L key rows into partial sums for BOTH outputs, hands the partner's partial sum
+// over through LDS, and inverse-transforms its own.
+// (evaluator.go:50-81; decomposer.go:55-66; fourier_ops.go:167-191)
 template <int L, int BGBIT>
 __device__ __forceinline__ void external_product_core(const DiffSource &S, uint32_t (&e)[16],
                                                       const cd *__restrict__ key_ip, /* &bsk[i][p] */
@@ -141,7 +136,6 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
                                                       uint32_t offset, int p, int lane)
 {
     cd keep[8], send[8];
-#ifndef TFHE_SERIAL_FFT
     // All L digit polynomials are transformed as one batch (fft512_forward_batch), then
     // multiplied into the two accumulators level by level.
     cd x[L][8];
@@ -171,6 +165,9 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
                 cfma(send[k], x[l][k], K.send[k]);
             }
         }
+        // Anchor the accumulators: pure arithmetic has no ordering against the loads below, and
+        // without this the compiler sinks the MAC past them (keeping the spectrum alive and spilling
+        // the prefetched keys).  Then refill the key registers for the next level / next CMUX step.
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             asm volatile("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
@@ -180,58 +177,13 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         else if (key_next) load_keys(K, key_next, p, lane);
         __builtin_amdgcn_sched_barrier(0);
     }
-#else
-#pragma unroll
-    for (int k = 0; k < 8; k++) keep[k] = send[k] = cd{0.0, 0.0};
-
-#pragma unroll
-    for (int l = 0; l < L; l++) {
-        cd x[8];
-        constexpr uint32_t mask = (1u << BGBIT) - 1u;
-        constexpr int half = 1 << (BGBIT - 1);
-        const int shift = 32 - (l + 1) * BGBIT;
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const uint32_t d0 = diff_coeff(S, 64 * a + lane), d1 = diff_coeff(S, 64 * a + lane + 512);
-            int dr = (int)(((d0 + offset) >> shift) & mask) - half;
-            int di = (int)(((d1 + offset) >> shift) & mask) - half;
-            x[a] = cd{(double)dr, (double)di};
-        }
-        fft512_forward(x, sc_mine, table, tw, lane);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            cfma(keep[k], x[k], K.keep[k]);
-            cfma(send[k], x[k], K.send[k]);
-        }
-        // Anchor the accumulators here: pure arithmetic has no ordering against the loads below,
-        // and without this the compiler sinks the MAC past them (keeping the spectrum alive and
-        // spilling the prefetched keys).
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            asm volatile("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
-        }
-        // refill the key registers for the next level (or the next CMUX step) right away
-        __builtin_amdgcn_sched_barrier(0);
-        if (l + 1 < L) load_keys(K, key_ip + (size_t)(l + 1) * 2 * 512, p, lane);
-        else if (key_next) load_keys(K, key_next, p, lane);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#endif
     // hand the partner's partial sum over
 #pragma unroll
     for (int k = 0; k < 8; k++) sc_mine[k * 64 + lane] = send[k];
-#ifndef ABLATE_BARRIER
     __syncthreads();
-#else
-    wave_lds_order();
-#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
-#ifndef ABLATE_BARRIER
     __syncthreads();
-#else
-    wave_lds_order();
-#endif
     fft512_inverse(keep, sc_mine, table, tw, lane);
 #pragma unroll
     for (int a = 0; a < 8; a++) {

@@ -68,12 +68,6 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 
 // A wave's DS operations are executed in issue order, so a wave-private LDS exchange only
 // needs the compiler kept from reordering/merging the accesses.
-#ifdef ABLATE_EXCHANGE
-#define TFHE_XCHG(stmt) for (int z_ = 0; z_ < 0; z_++) {}
-#else
-#define TFHE_XCHG(stmt) stmt
-#endif
-
 #ifndef TFHE_NO_XCHG_PRIO
 // waves issuing an LDS exchange run at raised priority so the exchange gets into the (CU-shared)
 // LDS pipe early and its latency overlaps the other waves' fp64 work (-4 % blind-rotate time when applied to the batched forward exchanges; the same on the
@@ -194,19 +188,19 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     dft8<1>(x);
     // exchange 1: (reg m, lane 8b+c) -> (reg b, lane 8m+c)
 #pragma unroll
-    TFHE_XCHG(for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];)
+    for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];
     wave_lds_order();
 #pragma unroll
-    TFHE_XCHG(for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];)
+    for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
     wave_lds_order();
     twist_pow<false>(x, tw.l2);
     dft8<1>(x);
     // exchange 2: (reg m', lane 8m+c) -> (reg c, lane 8m+m')
 #pragma unroll
-    TFHE_XCHG(for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];)
+    for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];
     wave_lds_order();
 #pragma unroll
-    TFHE_XCHG(for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];)
+    for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
     wave_lds_order();
     twist_pow<false>(x, tw.l3);
     dft8<1>(x);
@@ -229,10 +223,10 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
         dft8<1>(x[t]);
         TFHE_PRIO(3);
 #pragma unroll
-        TFHE_XCHG(for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];)
+        for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];
         wave_lds_order();
 #pragma unroll
-        TFHE_XCHG(for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];)
+        for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];
         wave_lds_order();
         TFHE_PRIO(0);
     }
@@ -242,10 +236,10 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
         dft8<1>(x[t]);
         TFHE_PRIO(3);
 #pragma unroll
-        TFHE_XCHG(for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];)
+        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];
         wave_lds_order();
 #pragma unroll
-        TFHE_XCHG(for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];)
+        for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];
         wave_lds_order();
         TFHE_PRIO(0);
     }
@@ -265,19 +259,19 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
     twist_pow<true>(x, tw.l3);
     // (reg c, lane 8m+m') -> (reg m', lane 8m+c)
 #pragma unroll
-    TFHE_XCHG(for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];)
+    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
     wave_lds_order();
 #pragma unroll
-    TFHE_XCHG(for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];)
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
     wave_lds_order();
     dft8<-1>(x);
     twist_pow<true>(x, tw.l2);
     // (reg b, lane 8m+c) -> (reg m, lane 8b+c)
 #pragma unroll
-    TFHE_XCHG(for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];)
+    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
     wave_lds_order();
 #pragma unroll
-    TFHE_XCHG(for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];)
+    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
     wave_lds_order();
     dft8<-1>(x);
 #pragma unroll
