@@ -211,3 +211,26 @@ def test_110bit_parameter_set(oracle, pkg):
         assert list(k.dec(out)) == [bool(TRUTH[op](bool(x), bool(y))) for x, y in zip(A, B)]
         assert np.array_equal(out[33], oracle.gate(k.p, k.bsk, k.ksk, op, a[33], b[33]))
     ck.close()
+
+
+def test_external_product_adversarial_extreme_within_one_ulp(pkg, oracle):
+    # with every digit = -32 and every key coefficient = -2^31 the fp64 pipeline's
+    # pre-rounding error reaches ~0.5, so results may be off by one torus ulp from the exact integer
+    # product -- for the reference's own FFT as well as for this one.  Random inputs stay bit-exact.
+    from conftest import gpu_params
+    p = oracle.params("128").small(1)
+    bsk_t = np.full((1, 6, 2, 1024), 0x80000000, np.uint32)
+    ksk = np.zeros((p.ksk_rows, p.n + 1), np.uint32)
+    ck = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
+    off = oracle.offset(p)
+    trl = np.full((1, 2, 1024), (0 - off) & 0xFFFFFFFF, np.uint32)       # d + offset = 0 -> every digit is -32
+    assert (oracle.decompose(p, trl[0][0]).view(np.int32) == -32).all()
+    got = ck.ctx.external_product_batch(0, trl)[0]
+    exact = oracle.external_product_exact(p, bsk_t[0], trl[0])
+    d = (got.astype(np.int64) - exact.astype(np.int64)) % 2**32
+    assert np.minimum(d, 2**32 - d).max() <= 1
+    bf = np.stack([oracle.to_fourier(x) for x in bsk_t[0].reshape(-1, 1024)]).reshape(6, 2, 1024)
+    ref = oracle.external_product(p, bf, trl[0])
+    d = (ref.astype(np.int64) - exact.astype(np.int64)) % 2**32
+    assert np.minimum(d, 2**32 - d).max() <= 1
+    ck.close()
