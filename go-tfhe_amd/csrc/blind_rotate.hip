@@ -8,19 +8,23 @@ namespace tfhe {
 
 void launch_blind_rotate(int shape, const BlindRotateArgs &a, int B, hipStream_t st)
 {
-    if (shape == 1)
-        hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a);
-    else
-        hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(256), 0, st, a);
+    switch (shape) {
+    case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a); break;
+    case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10>), dim3(B), dim3(128), 0, st, a); break;
+    case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_blind_rotate<1, 23>), dim3(B), dim3(128), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(256), 0, st, a); break;
+    }
 }
 
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
                              uint32_t offset, int B, hipStream_t st)
 {
-    if (shape == 1)
-        hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset);
-    else
-        hipLaunchKernelGGL((k_external_product_2048<22>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset);
+    switch (shape) {
+    case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
+    case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_external_product<2, 10>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
+    case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_external_product<1, 23>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
+    default: hipLaunchKernelGGL((k_external_product_2048<22>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
+    }
 }
 
 } // namespace tfhe

@@ -78,7 +78,7 @@ struct BlindRotateArgs {
     uint32_t offset;        // decomposition offset (cloudkey.go:60-71)
 };
 
-constexpr int kMaxLweDim = 1088;
+constexpr int kMaxLweDim = 1280;      // Uint7/8 use n = 1160 (params.go:444-510)
 
 // Key slices of one gadget level for one wave: 8 register-slices of the spectrum it keeps and
 // 8 of the spectrum it hands to its partner (64 VGPRs), fetched one level ahead of use so the
@@ -185,10 +185,14 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
     __syncthreads();
     fft512_inverse(keep, sc_mine, table, tw, lane);
+    // |v| <= 2L * N * (Bg/2) * 2^31: below 2^51 the 1.5*2^52 trick is exact (L=3, Bgbit=6: 2^48.6);
+    // the Uint1 / Uint3 shapes (L=2,Bgbit=10: 2^52; L=1,Bgbit=23: 2^64) need the wide form and sit in
+    // the tolerance regime, like the reference's own fp64 pipeline at those sets.
+    constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;
 #pragma unroll
     for (int a = 0; a < 8; a++) {
-        e[a] = round_to_torus_small(keep[a].re);
-        e[a + 8] = round_to_torus_small(keep[a].im);
+        e[a] = kSmall ? round_to_torus_small(keep[a].re) : round_to_torus_wide(keep[a].re);
+        e[a + 8] = kSmall ? round_to_torus_small(keep[a].im) : round_to_torus_wide(keep[a].im);
     }
 }
 

@@ -9,7 +9,12 @@
 #include "kernels.hpp"
 
 namespace tfhe {
-// shape 1: N=1024, L=3, Bgbit=6   shape 2: N=2048, L=1, Bgbit=22
+// Parameter shapes with kernels (tfhe_ctx_create picks one):
+enum Shape { kShapeN1024_L3_B6 = 1,   // 80/110/128-bit sets
+             kShapeN2048_L1_B22 = 2,  // Uint4, Uint5, Uint6 (and the shapes of Uint7/8)
+             kShapeN1024_L2_B10 = 3,  // Uint1
+             kShapeN1024_L1_B23 = 4 };// Uint3
+inline bool shape_is_1024(int shape) { return shape != kShapeN2048_L1_B22; }
 void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, hipStream_t st);
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
                              uint32_t offset, int B, hipStream_t st);

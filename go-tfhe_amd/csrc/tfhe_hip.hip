@@ -71,7 +71,7 @@ struct DevBuf {
 struct tfhe_ctx {
     tfhe_params P{};
     int device = 0;
-    int shape = 0;              // 1: N=1024,L=3,Bgbit=6   2: N=2048,L=1,Bgbit=22
+    int shape = 0;              // tfhe::Shape (launch_blind_rotate.hpp)
     uint32_t offset = 0;        // cloudkey.go:60-71
     int n1p = 0;                // padded LWE row length of the packed KSK
     hipStream_t stream = nullptr;
@@ -302,12 +302,14 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
 {
     if (!P || !out) return fail(TFHE_E_INVALID, "null argument");
     int shape = 0;
-    if (P->N == 1024 && P->Nbit == 10 && P->L == 3 && P->Bgbit == 6) shape = 1;
-    if (P->N == 2048 && P->Nbit == 11 && P->L == 1 && P->Bgbit == 22) shape = 2;
+    if (P->N == 1024 && P->Nbit == 10 && P->L == 3 && P->Bgbit == 6) shape = kShapeN1024_L3_B6;
+    if (P->N == 1024 && P->Nbit == 10 && P->L == 2 && P->Bgbit == 10) shape = kShapeN1024_L2_B10;
+    if (P->N == 1024 && P->Nbit == 10 && P->L == 1 && P->Bgbit == 23) shape = kShapeN1024_L1_B23;
+    if (P->N == 2048 && P->Nbit == 11 && P->L == 1 && P->Bgbit == 22) shape = kShapeN2048_L1_B22;
     if (!shape)
         return fail(TFHE_E_INVALID,
-                    "unsupported parameter shape N=%d L=%d Bgbit=%d (supported: N=1024,L=3,Bgbit=6 and N=2048,L=1,Bgbit=22)",
-                    P->N, P->L, P->Bgbit);
+                    "unsupported parameter shape N=%d L=%d Bgbit=%d (supported: N=1024 with (L,Bgbit) = (3,6), (2,10), (1,23); "
+                    "N=2048 with (1,22))", P->N, P->L, P->Bgbit);
     if (P->n < 1 || P->n >= kMaxLweDim) return fail(TFHE_E_INVALID, "LWE dimension %d out of range", P->n);
     if (P->basebit < 1 || P->t < 1 || P->basebit * P->t > 31 || (size_t)P->N * P->t > 9216)
         return fail(TFHE_E_INVALID, "unsupported key-switch shape basebit=%d t=%d", P->basebit, P->t);
@@ -377,7 +379,7 @@ int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
     DevBuf raw;
     if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bytes))) { raw.release(); return rc; }
     HIP_TRY(hipMemcpyAsync(raw.p, bsk, bytes, hipMemcpyHostToDevice, c->stream));
-    if (c->shape == 1)
+    if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_bsk_from_fourier, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
                            raw.as<double>(), c->bsk.as<cd>(), c->P.n, c->P.L);
     else
@@ -400,7 +402,7 @@ int tfhe_load_bsk_torus(tfhe_ctx *c, const uint32_t *bsk)
     DevBuf raw;
     if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bsk_elems(c->P) * sizeof(cd)))) { raw.release(); return rc; }
     HIP_TRY(hipMemcpyAsync(raw.p, bsk, bytes, hipMemcpyHostToDevice, c->stream));
-    if (c->shape == 1)
+    if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_bsk_from_torus, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
                            c->bsk.as<cd>(), c->tw.as<cd>(), c->P.L);
     else
@@ -457,10 +459,18 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
     hipStream_t st = c->stream;
     HIP_TRY(hipMemcpyAsync(d_s0.p, s0, (size_t)P.n * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_s1.p, s1, (size_t)P.N * 4, hipMemcpyHostToDevice, st));
-    if (c->shape == 1) {
+    if (shape_is_1024(c->shape)) {
         hipLaunchKernelGGL(k_keygen_s1_spectrum, dim3(1), dim3(64), 0, st, d_s1.as<uint32_t>(), d_spec.as<cd>(), c->tw.as<cd>());
-        hipLaunchKernelGGL((k_keygen_bsk<3, 6>), dim3(P.n * 2 * P.L), dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(),
-                           d_spec.as<cd>(), d_s0.as<uint32_t>(), alpha_lv1, seed);
+        const dim3 g(P.n * 2 * P.L);
+        if (c->shape == kShapeN1024_L3_B6)
+            hipLaunchKernelGGL((k_keygen_bsk<3, 6>), g, dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(), d_spec.as<cd>(),
+                               d_s0.as<uint32_t>(), alpha_lv1, seed);
+        else if (c->shape == kShapeN1024_L2_B10)
+            hipLaunchKernelGGL((k_keygen_bsk<2, 10>), g, dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(), d_spec.as<cd>(),
+                               d_s0.as<uint32_t>(), alpha_lv1, seed);
+        else
+            hipLaunchKernelGGL((k_keygen_bsk<1, 23>), g, dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(), d_spec.as<cd>(),
+                               d_s0.as<uint32_t>(), alpha_lv1, seed);
     } else {
         hipLaunchKernelGGL(k_keygen_s1_spectrum_2048, dim3(1), dim3(64), 0, st, d_s1.as<uint32_t>(), d_spec.as<cd>(), c->tw.as<cd>());
         hipLaunchKernelGGL((k_keygen_bsk_2048<22>), dim3(P.n * 2), dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(),
@@ -636,7 +646,7 @@ int tfhe_to_fourier_batch(tfhe_ctx *c, const uint32_t *polys, double *spectra, i
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
     if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t0.p, polys, pb, hipMemcpyHostToDevice, c->stream));
-    if (c->shape == 1)
+    if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_to_fourier, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(), c->s_t1.as<double>(),
                            c->tw.as<cd>());
     else
@@ -658,7 +668,7 @@ int tfhe_to_poly_batch(tfhe_ctx *c, const double *spectra, uint32_t *polys, int 
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
     if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t1.p, spectra, sb, hipMemcpyHostToDevice, c->stream));
-    if (c->shape == 1)
+    if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_to_poly, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
                            c->tw.as<cd>());
     else

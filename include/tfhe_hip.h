@@ -67,8 +67,10 @@ int tfhe_device_count(int *count);
 
 /* evaluator.NewEvaluator (evaluator.go:27-35) + the CloudKey fields that are pure
  * functions of the parameters (cloudkey.go:60-85: decomposition offset, gate test
- * vector).  Supported parameter shapes: N=1024 with L=3,Bgbit=6 (the 80/110/128-bit
- * sets) and N=2048 with L=1,Bgbit=22 (Uint5); anything else returns TFHE_E_INVALID. */
+ * vector).  Supported parameter shapes: N=1024 with (L,Bgbit) = (3,6) [80/110/128-bit],
+ * (2,10) [Uint1], (1,23) [Uint3]; N=2048 with (1,22) [Uint4, Uint5, and the shapes of
+ * Uint6-8]; any n < 1280, any key-switch (basebit, t) with N*t <= 9216.  Anything else
+ * (e.g. Uint2's N=512) returns TFHE_E_INVALID. */
 int tfhe_ctx_create(const tfhe_params *params, int device_id, tfhe_ctx **out);
 int tfhe_ctx_destroy(tfhe_ctx *ctx);
 int tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);

@@ -34,6 +34,17 @@ int orc_get_params(int which, orc_params *o)
     case 3: /* params/params.go:362-391 */
         *o = (orc_params){1071, 2048, 11, 1, 22, 6, 3, 7.088226765410429399593757e-08,
                           2.2204460492503131e-17}; return 0;
+    case 4: /* Uint1, params/params.go:194-232 */
+        *o = (orc_params){700, 1024, 10, 2, 10, 2, 8, 2.0e-5, 2.0e-8}; return 0;
+    case 5: /* Uint3, params/params.go:277-313 */
+        *o = (orc_params){820, 1024, 10, 1, 23, 6, 2, 0.00000251676160959795544987084234,
+                          0.00000000000000022204460492503131}; return 0;
+    case 6: /* Uint4, params/params.go:318-354 */
+        *o = (orc_params){820, 2048, 11, 1, 22, 5, 3, 0.00000251676160959795544987084234,
+                          0.00000000000000022204460492503131}; return 0;
+    case 7: /* Uint7 / Uint8 share this shape, params/params.go:444-521 */
+        *o = (orc_params){1160, 2048, 11, 1, 22, 7, 3, 1.966220007498402695211596e-08,
+                          2.2204460492503131e-17}; return 0;
     default: return -1;
     }
 }

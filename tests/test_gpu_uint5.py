@@ -1,4 +1,5 @@
-"""GPU parity at the Uint5 parameter set (N=2048, L=1, Bgbit=22; params.go:362-391): the
+"""GPU parity at the Uint parameter sets (Uint5: N=2048, L=1, Bgbit=22; params.go:362-391; plus
+Uint1/3/4 and the Uint7/8 shape at the end of the file): the
 programmable-bootstrap path (evaluator/programmable_bootstrap.go:93-115, BASELINE config 4).
 
 Tolerance regime: intermediate values reach ~2^58 > 2^53, so neither the Go
@@ -140,3 +141,50 @@ def test_pbs_full_uint5_batch512(oracle, pkg, keys_u5_full, ck_u5_full):
     # the oracle run on the same input decrypts identically (masks are not comparable)
     ref = oracle.bootstrap(k.p, k.bsk, k.ksk, cts[0], luts[0])
     assert oracle.decrypt_message(k.p, 32, k.s0, ref) == 5
+
+
+@pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint3", 8), ("uint4", 16)])
+def test_pbs_other_uint_sets(oracle, pkg, name, modulus):
+    # The other Uint sets the reference tests (params/uint_params_test.go:24-27): Uint1 (N=1024, L=2,
+    # Bgbit=10), Uint3 (N=1024, L=1, Bgbit=23), Uint4 (N=2048, L=1, Bgbit=22, basebit=5), full LWE dimension,
+    # cloud key generated on the GPU.  All three sit in the fp64 tolerance regime (values >= 2^52).
+    p = oracle.params(name)
+    rng = oracle.rng(0x7F4E0008)
+    s0, s1 = oracle.keygen_secret(p, rng)
+    ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=11)
+    vals = list(range(modulus)) if modulus <= 8 else [0, 1, 2, modulus // 2, modulus - 3, modulus - 2, modulus - 1]
+    cts = np.stack([oracle.encrypt_message(p, rng, m, modulus, s0) for m in vals])
+    for f in (lambda x: x, lambda x: modulus - 1 - x, lambda x: x % (modulus // 2)):
+        lut = oracle.lut_generate(p, [f(x) for x in range(modulus)])
+        out = ck.ctx.bootstrap_batch(cts, lut)
+        dec = [oracle.decrypt_message(p, modulus, s0, np.ascontiguousarray(o)) for o in out]
+        assert dec == [f(m) for m in vals], (name, dec)
+    ck.close()
+
+
+def test_external_product_uint1_uint3_tolerance(oracle, pkg):
+    for name, tol in (("uint1", 2**4), ("uint3", 2**12)):
+        k = KeySet(oracle, name, 0x7F4E0009, n_override=4)
+        ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+        trl = rand_u32(np.random.RandomState(36), (3, 2, 1024))
+        got = ck.ctx.external_product_batch(2, trl)
+        for b in range(3):
+            exact = oracle.external_product_exact(k.p, k.bsk_torus[2], trl[b])
+            ref = oracle.external_product(k.p, k.bsk[2], trl[b])
+            assert circ_dist(got[b], exact).max() <= tol, (name, circ_dist(got[b], exact).max())
+            assert circ_dist(ref, exact).max() <= tol, (name, circ_dist(ref, exact).max())
+        ck.close()
+
+
+def test_uint7_shape_runs(oracle, pkg):
+    # Uint7/8 (n=1160, basebit=7): the reference skips their PBS tests (extended LUTs unimplemented,
+    # uint_params_test.go:29-31); the shape is accepted and a plain m=32 LUT bootstraps correctly.
+    p = oracle.params("uint7").small(1160)
+    rng = oracle.rng(0x7F4E000A)
+    s0, s1 = oracle.keygen_secret(p, rng)
+    ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=12)
+    lut = oracle.lut_generate(p, [(x + 3) % 32 for x in range(32)])
+    cts = np.stack([oracle.encrypt_message(p, rng, m, 32, s0) for m in (0, 9, 31)])
+    out = ck.ctx.bootstrap_batch(cts, lut)
+    assert [oracle.decrypt_message(p, 32, s0, np.ascontiguousarray(o)) for o in out] == [3, 12, 2]
+    ck.close()

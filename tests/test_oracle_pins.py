@@ -187,6 +187,20 @@ def test_pbs_uint5_decrypt(oracle, fname):
         assert oracle.decrypt_message(ks.p, 32, ks.s0, out) == f(m), (fname, m)
 
 
+@pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint3", 8), ("uint4", 16)])
+def test_pbs_other_uint_sets_decrypt(oracle, name, modulus):
+    # params/uint_params_test.go:24-27: Uint1 (m=2), Uint3 (m=8), Uint4 (m=16); Uint2 is N=512 (no kernel)
+    from conftest import KeySet
+    ks = KeySet(oracle, name, 0x7F4E0007, n_override=40, torus=False)
+    vals = list(range(modulus)) if modulus <= 8 else [0, 1, 2, modulus // 2, modulus - 3, modulus - 2, modulus - 1]
+    for f in (lambda x: x, lambda x: modulus - 1 - x, lambda x: x % (modulus // 2)):
+        lut = oracle.lut_generate(ks.p, [f(x) for x in range(modulus)])
+        for m in vals:
+            ct = oracle.encrypt_message(ks.p, ks.rng, m, modulus, ks.s0)
+            out = oracle.bootstrap(ks.p, ks.bsk, ks.ksk, ct, lut)
+            assert oracle.decrypt_message(ks.p, modulus, ks.s0, out) == f(m), (name, m)
+
+
 def test_pbs_binary_80bit(oracle, keys80):
     # evaluator/programmable_bootstrap_test.go:13-188: identity / NOT / constant with m = 2
     k = keys80
