@@ -317,7 +317,12 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(TFHE_E_INVALID, "device %d not present (%d visible)", device_id, ndev);
     HIP_TRY(hipSetDevice(device_id));
-    tfhe_ctx *c = new tfhe_ctx;
+    // every failure path below releases what was created so far (tfhe_ctx_destroy is null-tolerant)
+    struct Guard {
+        tfhe_ctx *c;
+        ~Guard() { if (c) tfhe_ctx_destroy(c); }
+    } guard{new tfhe_ctx};
+    tfhe_ctx *c = guard.c;
     c->P = *P; c->device = device_id; c->shape = shape;
     c->n1p = (P->n + 1 + 3) & ~3;
     for (int i = 0; i < P->L; i++) c->offset += (1u << (P->Bgbit - 1)) * (1u << (32 - (i + 1) * P->Bgbit));
@@ -326,12 +331,13 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
     std::vector<cd> tw = make_twiddles(P->N);
     int rc;
-    if ((rc = c->tw.reserve(tw.size() * sizeof(cd)))) { delete c; return rc; }
+    if ((rc = c->tw.reserve(tw.size() * sizeof(cd)))) return rc;
     HIP_TRY(hipMemcpy(c->tw.p, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
     std::vector<uint32_t> tv(2 * (size_t)P->N, 0u);              // cloudkey.go:74-85
     for (int j = 0; j < P->N; j++) tv[P->N + j] = 0x20000000u;
-    if ((rc = c->gate_tv.reserve(tv.size() * sizeof(uint32_t)))) { delete c; return rc; }
+    if ((rc = c->gate_tv.reserve(tv.size() * sizeof(uint32_t)))) return rc;
     HIP_TRY(hipMemcpy(c->gate_tv.p, tv.data(), tv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    guard.c = nullptr;
     *out = c;
     return TFHE_OK;
 }
@@ -340,7 +346,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
 {
     if (!c) return TFHE_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->bsk, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
                       &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3})
         b->release();
