@@ -6,13 +6,31 @@
 
 namespace tfhe {
 
-void launch_blind_rotate(int shape, const BlindRotateArgs &a, int B, hipStream_t st)
+void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cus, hipStream_t st)
 {
-    switch (shape) {
-    case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6>), dim3(B), dim3(128), 0, st, a); break;
-    case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10>), dim3(B), dim3(128), 0, st, a); break;
-    case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_blind_rotate<1, 23>), dim3(B), dim3(128), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_blind_rotate_2048<22>), dim3(B), dim3(256), 0, st, a); break;
+    // One launch covers at most the number of co-resident workgroups (28.8 KB LDS / 256 VGPRs -> 4 per CU
+    // for N=1024; 55 KB LDS -> 2 per CU for N=2048).  All workgroups of such a launch walk the CMUX index in
+    // near lock-step, so bsk[i] is shared through L2.  A single 16k-item launch de-synchronises (later
+    // workgroups start as earlier ones finish) and becomes Infinity-Cache-bandwidth bound: 7.7 us per
+    // bootstrap instead of 6.6; a persistent in-kernel item loop was tried and cost 9 % at B = 1024.
+    const int cap = (shape_is_1024(shape) ? 4 : 2) * num_cus;
+    const size_t n1 = (size_t)a0.n + 1;
+    const size_t trl = shape_is_1024(shape) ? 2 * 1024 : 2 * 2048;
+    for (int base = 0; base < B; base += cap) {
+        const int cnt = B - base < cap ? B - base : cap;
+        BlindRotateArgs a = a0;
+        a.in0 = a0.in0 + base * n1;
+        if (a0.in1) a.in1 = a0.in1 + base * n1;
+        if (a0.ops) a.ops = a0.ops + base;
+        a.tv = a0.tv + (size_t)base * a0.tv_stride;
+        a.out = a0.out + base * trl;
+        const dim3 g(cnt);
+        switch (shape) {
+        case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6>), g, dim3(128), 0, st, a); break;
+        case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10>), g, dim3(128), 0, st, a); break;
+        case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_blind_rotate<1, 23>), g, dim3(128), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_blind_rotate_2048<22>), g, dim3(256), 0, st, a); break;
+        }
     }
 }
 

@@ -74,6 +74,7 @@ struct tfhe_ctx {
     int shape = 0;              // tfhe::Shape (launch_blind_rotate.hpp)
     uint32_t offset = 0;        // cloudkey.go:60-71
     int n1p = 0;                // padded LWE row length of the packed KSK
+    int num_cus = 256;          // hipDeviceProp_t.multiProcessorCount
     hipStream_t stream = nullptr;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool ev_valid[2] = {false, false};
@@ -172,7 +173,7 @@ int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in
     hipEvent_t stop;
     int trc = timing_begin(c, 0, st, &stop);
     if (trc) return trc;
-    launch_blind_rotate(c->shape, a, B, st);
+    launch_blind_rotate(c->shape, a, B, c->num_cus, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(stop, st));
     c->ev_valid[0] = !c->timing;
@@ -326,6 +327,11 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     c->P = *P; c->device = device_id; c->shape = shape;
     c->n1p = (P->n + 1 + 3) & ~3;
     for (int i = 0; i < P->L; i++) c->offset += (1u << (P->Bgbit - 1)) * (1u << (32 - (i + 1) * P->Bgbit));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
