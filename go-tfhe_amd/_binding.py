@@ -69,6 +69,8 @@ def load_library():
         "tfhe_to_fourier_batch": [vp, u32p, f64p, C.c_int],
         "tfhe_to_poly_batch": [vp, f64p, u32p, C.c_int],
         "tfhe_last_kernel_ms": [vp, C.c_int, C.POINTER(C.c_float)],
+        "tfhe_host_alloc": [C.c_size_t, C.POINTER(vp)],
+        "tfhe_host_free": [vp],
         "tfhe_timing_enable": [vp, C.c_int],
         "tfhe_timing_read": [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     }
@@ -105,6 +107,33 @@ def _devptr(t):
     if not t.is_cuda or not t.is_contiguous():
         raise ValueError("device variants need contiguous GPU tensors")
     return C.c_void_p(t.data_ptr())
+
+
+class PinnedArray:
+    """numpy view of a page-locked host buffer from tfhe_host_alloc (fast path of the host-pointer ABI)."""
+
+    def __init__(self, shape, dtype=np.uint32):
+        lib = load_library()
+        self._lib = lib
+        self._p = C.c_void_p()
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        rc = lib.tfhe_host_alloc(max(nbytes, 1), C.byref(self._p))
+        if rc != 0:
+            raise TfheError(rc, lib.tfhe_last_error().decode())
+        buf = (C.c_char * max(nbytes, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if self._p is not None and self._p.value:
+            self.array = None
+            self._lib.tfhe_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -211,14 +240,17 @@ class Context:
         self._check(self._lib.tfhe_extract_keyswitch_batch(self._h, _p32(trlwe), _p32(out), B))
         return out
 
-    def gate_batch(self, ops, a, b, c=None):
+    def gate_batch(self, ops, a, b, c=None, out=None):
         p = self.params
         a, b = _u32(a), _u32(b)
         B = a.shape[0]
         if a.shape != (B, p.n + 1) or b.shape != a.shape:
             raise ValueError(f"operand shapes {a.shape} {b.shape}")
         c = _u32(c, a.shape) if c is not None else None
-        out = np.empty_like(a)
+        if out is None:
+            out = np.empty_like(a)
+        elif out.shape != a.shape or out.dtype != np.uint32 or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("bad output array")
         if isinstance(ops, str):
             opp, uni = None, OPS[ops]
         else:

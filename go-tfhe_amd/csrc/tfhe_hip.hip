@@ -703,6 +703,21 @@ int tfhe_last_kernel_ms(tfhe_ctx *c, int which, float *ms)
     return TFHE_OK;
 }
 
+int tfhe_host_alloc(size_t bytes, void **out)
+{
+    if (!out || bytes == 0) return fail(TFHE_E_INVALID, "bad argument");
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return TFHE_OK;
+}
+
+int tfhe_host_free(void *p)
+{
+    if (!p) return TFHE_OK;
+    HIP_TRY(hipHostFree(p));
+    return TFHE_OK;
+}
+
 int tfhe_timing_enable(tfhe_ctx *c, int on)
 {
     int rc = check_ctx(c);

@@ -155,6 +155,14 @@ int tfhe_to_poly_batch(tfhe_ctx *ctx, const double *spectra, uint32_t *polys, in
  * which: 0 = blind rotate, 1 = sample-extract + key switch. */
 int tfhe_last_kernel_ms(tfhe_ctx *ctx, int which, float *ms);
 
+/* Page-locked host buffers for the host-pointer entry points.  The Go shim flattens ciphertexts
+ * anyway (cgo cannot pass []*TLWELv0); flattening INTO a buffer from tfhe_host_alloc lets the
+ * transfers run as true asynchronous DMA at PCIe speed instead of through the runtime's pageable
+ * staging path (measured: 1024 NAND gates 9.3 ms -> see DESIGN.md).  Plain malloc'ed pointers
+ * remain valid everywhere. */
+int tfhe_host_alloc(size_t bytes, void **out);
+int tfhe_host_free(void *p);
+
 /* Cumulative per-kernel timing for benchmarks: while enabled, every launch of the two path
  * kernels is bracketed by its own HIP event pair on the stream it is launched on.
  * tfhe_timing_read blocks until those launches have finished, returns their count and summed

@@ -234,3 +234,19 @@ def test_external_product_adversarial_extreme_within_one_ulp(pkg, oracle):
     d = (ref.astype(np.int64) - exact.astype(np.int64)) % 2**32
     assert np.minimum(d, 2**32 - d).max() <= 1
     ck.close()
+
+
+def test_pinned_host_buffers(oracle, keys_small, ck_small, pkg):
+    # tfhe_host_alloc / tfhe_host_free: page-locked operands and outputs through the host-pointer ABI
+    k = keys_small
+    rs = np.random.RandomState(23)
+    B = 40
+    a, b = rand_u32(rs, (B, k.p.n + 1)), rand_u32(rs, (B, k.p.n + 1))
+    pa, pb, po = pkg.PinnedArray(a.shape), pkg.PinnedArray(a.shape), pkg.PinnedArray(a.shape)
+    pa.array[...] = a
+    pb.array[...] = b
+    ck_small.ctx.gate_batch("XOR", pa.array, pb.array, out=po.array)
+    want, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, "XOR", a, b)
+    assert np.array_equal(po.array, want)
+    for x in (pa, pb, po):
+        x.free()
