@@ -137,7 +137,9 @@ int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, 
  *   a, b: [B][n+1]; c: [B][n+1], required iff any op is TFHE_OP_MUX (3 bootstraps,
  *   gates.go:107-114), may be NULL otherwise.
  * Batch XNOR follows the tested scalar gates.XNOR (+1/4, gates.go:52-58), not
- * BatchXNOR's -1/4 (gates.go:293), which computes XOR. */
+ * BatchXNOR's -1/4 (gates.go:293), which computes XOR.
+ * The _dev variant is enqueue-only for a uniform op; with per-item op codes it copies them
+ * back and synchronises the stream once (the MUX items have to be split out on the host). */
 int tfhe_gate_batch(tfhe_ctx *ctx, const uint8_t *ops, int op_uniform, const uint32_t *a,
                     const uint32_t *b, const uint32_t *c, uint32_t *out, int B);
 int tfhe_gate_batch_dev(tfhe_ctx *ctx, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a,
