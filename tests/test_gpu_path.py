@@ -250,3 +250,18 @@ def test_pinned_host_buffers(oracle, keys_small, ck_small, pkg):
     assert np.array_equal(po.array, want)
     for x in (pa, pb, po):
         x.free()
+
+
+def test_batch_larger_than_one_launch_with_per_item_testvec(oracle, keys_small, ck_small):
+    # > 1024 items are issued as several launches (launch_blind_rotate): operand / op / test-vector offsets
+    k = keys_small
+    rs = np.random.RandomState(24)
+    B = 1024 + 77
+    cts = rand_u32(rs, (B, k.p.n + 1))
+    tvs = rand_u32(rs, (B, 2, 1024))
+    got = ck_small.ctx.blind_rotate_batch(cts, tvs)
+    for b in (0, 1023, 1024, 1025, B - 1):
+        assert np.array_equal(got[b], oracle.blind_rotate(k.p, k.bsk, cts[b], tvs[b])), b
+    out = ck_small.ctx.bootstrap_batch(cts, tvs)
+    for b in (5, 1024, B - 1):
+        assert np.array_equal(out[b], oracle.bootstrap(k.p, k.bsk, k.ksk, cts[b], tvs[b])), b
