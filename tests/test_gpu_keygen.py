@@ -67,7 +67,7 @@ def test_noise_free_key_matches_oracle_noise_floor(oracle, pkg):
     dev_cpu = circ_dist([oracle.phase(p, s0, np.ascontiguousarray(o)) for o in out2], ideal)
     ck2.close()
     assert dev_gpu.max() < 2**27 and dev_cpu.max() < 2**27
-    assert 0.5 < dev_gpu.mean() / dev_cpu.mean() < 2.0, (dev_gpu.mean(), dev_cpu.mean())
+    assert 1.0 / 3.0 < dev_gpu.mean() / dev_cpu.mean() < 3.0, (dev_gpu.mean(), dev_cpu.mean())
 
 
 def test_gpu_generated_key_uint5_pbs(oracle, pkg):
