@@ -10,7 +10,6 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -48,6 +47,10 @@ int fail(int code, const char *fmt, ...)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }      // locals are released on every early-return path
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return TFHE_OK;
@@ -193,15 +196,11 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     if (trc) return trc;
     // base-4 sets: tiled kernel (key rows shared by 32 ciphertexts); needs a full row in 192 lanes
     constexpr int kT = 32, kIC = 32;
-    if (c->P.basebit == 2 && c->n1p <= 768 && c->P.N % kIC == 0 && B >= kT && !getenv("TFHE_KS_GATHER")) {
+    // (IC = 16 / 64 / 128 measured 0.80 / 0.68 / 1.07 ms against 0.71 ms for 32 on 1024 ciphertexts)
+    if (c->P.basebit == 2 && c->n1p <= 768 && c->P.N % kIC == 0 && B >= kT) {
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
-        const char *icv = getenv("TFHE_KS_IC");
-        const int ic = icv ? atoi(icv) : kIC;
-        if (ic == 64) hipLaunchKernelGGL((k_keyswitch_tiled<kT, 64>), dim3((B + kT - 1) / kT, c->P.N / 64), dim3(192), 0, st, a, B);
-        else if (ic == 128) hipLaunchKernelGGL((k_keyswitch_tiled<kT, 128>), dim3((B + kT - 1) / kT, c->P.N / 128), dim3(192), 0, st, a, B);
-        else if (ic == 16) hipLaunchKernelGGL((k_keyswitch_tiled<kT, 16>), dim3((B + kT - 1) / kT, c->P.N / 16), dim3(192), 0, st, a, B);
-        else hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((B + kT - 1) / kT, c->P.N / kIC), dim3(192), 0, st, a, B);
+        hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((B + kT - 1) / kT, c->P.N / kIC), dim3(192), 0, st, a, B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(stop, st));
         c->ev_valid[1] = !c->timing;
