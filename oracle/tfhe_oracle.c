@@ -45,6 +45,10 @@ int orc_get_params(int which, orc_params *o)
     case 7: /* Uint7 / Uint8 share this shape, params/params.go:444-521 */
         *o = (orc_params){1160, 2048, 11, 1, 22, 7, 3, 1.966220007498402695211596e-08,
                           2.2204460492503131e-17}; return 0;
+    case 8: /* Uint2, params/params.go:236-265.  The comment there mentions GLWE rank 3 upstream, but
+             * the reference's parameter structs carry no rank and the set runs at rank 1 like the rest. */
+        *o = (orc_params){687, 512, 9, 1, 18, 4, 3, 0.00002120846893069971872305794214,
+                          0.00000000000231841227527049948463}; return 0;
     default: return -1;
     }
 }

@@ -44,7 +44,7 @@ typedef struct {
 
 /* Named sets: 0 = 80-bit (params.go:83-112), 1 = 110-bit (:117-146),
  * 2 = 128-bit (:151-180), 3 = Uint5/Uint6 (:362-439), 4 = Uint1 (:194-232), 5 = Uint3 (:277-313),
- * 6 = Uint4 (:318-354), 7 = Uint7/Uint8 (:444-521). Returns 0 on success. */
+ * 6 = Uint4 (:318-354), 7 = Uint7/Uint8 (:444-521), 8 = Uint2 (:236-265). Returns 0 on success. */
 int orc_get_params(int which, orc_params *out);
 
 /* ---- scalar helpers ---------------------------------------------------- */

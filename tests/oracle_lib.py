@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB = os.path.join(ORACLE_DIR, "libtfhe_oracle.so")
 
-PARAM_SETS = {"80": 0, "110": 1, "128": 2, "uint5": 3, "uint6": 3, "uint1": 4, "uint3": 5, "uint4": 6, "uint7": 7, "uint8": 7}
+PARAM_SETS = {"80": 0, "110": 1, "128": 2, "uint5": 3, "uint6": 3, "uint1": 4, "uint3": 5, "uint4": 6, "uint7": 7, "uint8": 7, "uint2": 8}
 OPS = {"NAND": 0, "AND": 1, "OR": 2, "XOR": 3, "XNOR": 4, "NOR": 5,
        "ANDNY": 6, "ANDYN": 7, "ORNY": 8, "ORYN": 9, "MUX": 10}
 

@@ -18,14 +18,16 @@ def test_f64_to_torus_kat(oracle, d, want):
 
 def test_params_and_offset(oracle):
     # params/params_test.go:9-102 (N / n per level) and cloudkey.go:60-71
-    for name, n, N, t in [("80", 550, 1024, 7), ("110", 630, 1024, 8), ("128", 700, 1024, 9), ("uint5", 1071, 2048, 3)]:
+    # last row: params/uint_params_test.go:228 {"Uint2", SecurityUint2, 512, 687, 4}
+    for name, n, N, t in [("80", 550, 1024, 7), ("110", 630, 1024, 8), ("128", 700, 1024, 9), ("uint5", 1071, 2048, 3),
+                          ("uint2", 687, 512, 3)]:
         p = oracle.params(name)
         assert (p.n, p.N, p.t) == (n, N, t)
     assert oracle.offset(oracle.params("128")) == 0x82080000
     assert oracle.offset(oracle.params("uint5")) == 0x80000000
 
 
-@pytest.mark.parametrize("N", [1024, 2048])
+@pytest.mark.parametrize("N", [512, 1024, 2048])
 def test_fft_round_trip(oracle, N):
     # poly/poly_test.go:10-33 allows |diff| <= 10; the restatement is exact on 32-bit inputs
     rs = np.random.RandomState(N)
@@ -33,7 +35,7 @@ def test_fft_round_trip(oracle, N):
     assert np.array_equal(oracle.to_poly(oracle.to_fourier(p)), p)
 
 
-@pytest.mark.parametrize("N", [1024, 2048])
+@pytest.mark.parametrize("N", [512, 1024, 2048])
 def test_fft_slot_semantics(oracle, N):
     # slot s holds P(zeta^(1 - 4 bitrev(s))), zeta = exp(i pi / N)  
     rs = np.random.RandomState(7)
@@ -187,9 +189,9 @@ def test_pbs_uint5_decrypt(oracle, fname):
         assert oracle.decrypt_message(ks.p, 32, ks.s0, out) == f(m), (fname, m)
 
 
-@pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint3", 8), ("uint4", 16)])
+@pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint2", 4), ("uint3", 8), ("uint4", 16)])
 def test_pbs_other_uint_sets_decrypt(oracle, name, modulus):
-    # params/uint_params_test.go:24-27: Uint1 (m=2), Uint3 (m=8), Uint4 (m=16); Uint2 is N=512 (no kernel)
+    # params/uint_params_test.go:24-27: Uint1 (m=2), Uint2 (m=4, N=512), Uint3 (m=8), Uint4 (m=16)
     from conftest import KeySet
     ks = KeySet(oracle, name, 0x7F4E0007, n_override=40, torus=False)
     vals = list(range(modulus)) if modulus <= 8 else [0, 1, 2, modulus // 2, modulus - 3, modulus - 2, modulus - 1]
