@@ -3,6 +3,7 @@
 #include "launch_blind_rotate.hpp"
 
 #include "kernels_n2048.hpp"
+#include "kernels_n512.hpp"
 
 namespace tfhe {
 
@@ -13,9 +14,10 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
     // near lock-step, so bsk[i] is shared through L2.  A single 16k-item launch de-synchronises (later
     // workgroups start as earlier ones finish) and becomes Infinity-Cache-bandwidth bound: 7.7 us per
     // bootstrap instead of 6.6; a persistent in-kernel item loop was tried and cost 9 % at B = 1024.
-    const int cap = (shape_is_1024(shape) ? 4 : 2) * num_cus;
+    // N=512: one wave and 16 KB LDS per bootstrap, 2 waves per SIMD -> 8 per CU.
+    const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 4 : 2) * num_cus;
     const size_t n1 = (size_t)a0.n + 1;
-    const size_t trl = shape_is_1024(shape) ? 2 * 1024 : 2 * 2048;
+    const size_t trl = shape_is_512(shape) ? 2 * 512 : shape_is_1024(shape) ? 2 * 1024 : 2 * 2048;
     for (int base = 0; base < B; base += cap) {
         const int cnt = B - base < cap ? B - base : cap;
         BlindRotateArgs a = a0;
@@ -29,6 +31,7 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6>), g, dim3(128), 0, st, a); break;
         case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10>), g, dim3(128), 0, st, a); break;
         case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_blind_rotate<1, 23>), g, dim3(128), 0, st, a); break;
+        case kShapeN512_L1_B18: hipLaunchKernelGGL((k_blind_rotate_512<18>), g, dim3(64), 0, st, a); break;
         default: hipLaunchKernelGGL((k_blind_rotate_2048<22>), g, dim3(256), 0, st, a); break;
         }
     }
@@ -41,6 +44,7 @@ void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_ind
     case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_external_product<3, 6>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
     case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_external_product<2, 10>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
     case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_external_product<1, 23>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
+    case kShapeN512_L1_B18: hipLaunchKernelGGL((k_external_product_512<18>), dim3(B), dim3(64), 0, st, bsk, tw, key_index, in, out, offset); break;
     default: hipLaunchKernelGGL((k_external_product_2048<22>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
     }
 }

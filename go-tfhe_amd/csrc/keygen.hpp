@@ -15,6 +15,7 @@
 
 #include "kernels.hpp"
 #include "kernels_n2048.hpp"
+#include "kernels_n512.hpp"
 
 namespace tfhe {
 
@@ -135,6 +136,53 @@ static __global__ __launch_bounds__(64) void k_keygen_s1_spectrum(const uint32_t
     fft512_forward(x, sc, twt, tw, lane);
 #pragma unroll
     for (int k = 0; k < 8; k++) out[k * 64 + lane] = x[k];
+}
+
+// ---- N = 512 (L = 1): one wave per TRGSW sample, half-wave h encrypts row h (0: gadget on A, 1: on B).
+//      The secret-key spectrum comes from k_spectra_512 ([8][32]).
+template <int BGBIT>
+static __global__ __launch_bounds__(64) void k_keygen_bsk_512(cd *__restrict__ bsk, const cd *__restrict__ twt,
+                                                               const cd *__restrict__ s1_spec /* [8][32] */,
+                                                               const uint32_t *__restrict__ s0, double alpha, uint64_t seed)
+{
+    __shared__ cd sc[kScratchSlots];
+    const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
+    const int i = blockIdx.x, row = 2 * i + h;
+    cd *sch = sc + h * kHalfScratch;
+    LaneTwiddles512 tw;
+    load_lane_twiddles_512(tw, twt, hl);
+    uint32_t a[16], e[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int j = q < 8 ? 32 * q + hl : 32 * (q - 8) + hl + 256;
+        uniform_and_gaussian(seed, kStreamBskA, (uint64_t)row * 512 + j, alpha, a[q], e[q]);
+    }
+    cd x[8], as[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x[k] = cd{(double)(int32_t)a[k], (double)(int32_t)a[k + 8]};
+    fft256_forward(x, sch, twt, tw, hl);
+#pragma unroll
+    for (int k = 0; k < 8; k++) as[k] = cmul(x[k], s1_spec[k * 32 + hl]);
+    fft256_inverse(as, sch, twt, tw, hl);                       // A * s1 (exact: |.| < 2^41)
+    uint32_t b[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        b[k] = round_to_torus_small(as[k].re) + e[k];
+        b[k + 8] = round_to_torus_small(as[k].im) + e[k + 8];
+    }
+    const uint32_t g = s0[i] << (32 - BGBIT);                   // trgsw.go:51-54 with l = 0
+    cd y[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) y[k] = cd{(double)(int32_t)b[k], (double)(int32_t)b[k + 8]};
+    if (h == 1 && hl == 0) y[0].re = (double)(int32_t)(b[0] + g);
+    fft256_forward(y, sch, twt, tw, hl);
+    const double a0_fix = h == 0 ? ((double)(int32_t)(a[0] + g) - (double)(int32_t)a[0]) : 0.0;
+    const double add = __shfl(a0_fix, 32 * h);                  // coefficient 0 lives in lane hl = 0 of the half
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        bsk[bsk_index_512(i, h, 0, k, hl)] = cd{x[k].re + add, x[k].im};
+        bsk[bsk_index_512(i, h, 1, k, hl)] = y[k];
+    }
 }
 
 // ---- N = 2048 (L = 1)

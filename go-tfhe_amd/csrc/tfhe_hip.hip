@@ -17,6 +17,7 @@
 
 #include "kernels.hpp"
 #include "kernels_n2048.hpp"
+#include "kernels_n512.hpp"
 #include "launch_blind_rotate.hpp"
 #include "keygen.hpp"
 
@@ -108,13 +109,29 @@ hipStream_t pick(tfhe_ctx *, void *stream) { return (hipStream_t)stream; }
 std::vector<cd> make_twiddles(int N)
 {
     const int H = N / 1024;
-    std::vector<cd> t((size_t)kTwCount1024 * H);
     const long double pi = 3.14159265358979323846264338327950288L;
     auto zeta = [&](long e) {
         e %= 2L * N; if (e < 0) e += 2L * N;
         long double a = pi * (long double)e / (long double)N;
         return cd{(double)cosl(a), (double)sinl(a)};
     };
+    if (N == 512) {                                       // layout: kernels_n512.hpp
+        std::vector<cd> t(kTwCount512);
+        for (int a = 0; a < 8; a++) {
+            t[a] = zeta(32L * a);
+            cd c = zeta(-32L * a);
+            t[8 + a] = cd{c.re / 256.0, c.im / 256.0};
+        }
+        for (int hl = 0; hl < 32; hl++) {
+            const int m = hl >> 2, i = hl & 3;
+            for (int b = 0; b < 8; b++) t[kTw512Level2 + b * 32 + hl] = zeta(4L * b * (1 + 4 * m));
+            for (int q = 0; q < 2; q++)
+                for (int c = 0; c < 4; c++)
+                    t[kTw512Level3 + (4 * q + c) * 32 + hl] = zeta((long)c * (1 + 4 * (m + 8 * (4 * q + i))));
+        }
+        return t;
+    }
+    std::vector<cd> t((size_t)kTwCount1024 * H);
     for (int h = 0; h < H; h++) {
         cd *T = t.data() + (size_t)h * kTwCount1024;
         for (int a = 0; a < 8; a++) {
@@ -306,10 +323,11 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     if (P->N == 1024 && P->Nbit == 10 && P->L == 2 && P->Bgbit == 10) shape = kShapeN1024_L2_B10;
     if (P->N == 1024 && P->Nbit == 10 && P->L == 1 && P->Bgbit == 23) shape = kShapeN1024_L1_B23;
     if (P->N == 2048 && P->Nbit == 11 && P->L == 1 && P->Bgbit == 22) shape = kShapeN2048_L1_B22;
+    if (P->N == 512 && P->Nbit == 9 && P->L == 1 && P->Bgbit == 18) shape = kShapeN512_L1_B18;
     if (!shape)
         return fail(TFHE_E_INVALID,
                     "unsupported parameter shape N=%d L=%d Bgbit=%d (supported: N=1024 with (L,Bgbit) = (3,6), (2,10), (1,23); "
-                    "N=2048 with (1,22))", P->N, P->L, P->Bgbit);
+                    "N=2048 with (1,22); N=512 with (1,18))", P->N, P->L, P->Bgbit);
     if (P->n < 1 || P->n >= kMaxLweDim) return fail(TFHE_E_INVALID, "LWE dimension %d out of range", P->n);
     if (P->basebit < 1 || P->t < 1 || P->basebit * P->t > 31 || (size_t)P->N * P->t > 9216)
         return fail(TFHE_E_INVALID, "unsupported key-switch shape basebit=%d t=%d", P->basebit, P->t);
@@ -393,6 +411,9 @@ int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
     if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_bsk_from_fourier, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
                            raw.as<double>(), c->bsk.as<cd>(), c->P.n, c->P.L);
+    else if (shape_is_512(c->shape))
+        hipLaunchKernelGGL(k_bsk_from_fourier_512, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
+                           raw.as<double>(), c->bsk.as<cd>(), c->P.n);
     else
         hipLaunchKernelGGL(k_bsk_from_fourier_2048, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
                            raw.as<double>(), c->bsk.as<cd>(), c->P.n);
@@ -416,6 +437,9 @@ int tfhe_load_bsk_torus(tfhe_ctx *c, const uint32_t *bsk)
     if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_bsk_from_torus, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
                            c->bsk.as<cd>(), c->tw.as<cd>(), c->P.L);
+    else if (shape_is_512(c->shape))     // reference order (i, row, part) is already the device order
+        hipLaunchKernelGGL(k_spectra_512, dim3((unsigned)((polys + 1) / 2)), dim3(64), 0, c->stream, raw.as<uint32_t>(),
+                           c->bsk.as<cd>(), c->tw.as<cd>(), (int)polys);
     else
         hipLaunchKernelGGL(k_bsk_from_torus_2048, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
                            c->bsk.as<cd>(), c->tw.as<cd>());
@@ -482,6 +506,10 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
         else
             hipLaunchKernelGGL((k_keygen_bsk<1, 23>), g, dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(), d_spec.as<cd>(),
                                d_s0.as<uint32_t>(), alpha_lv1, seed);
+    } else if (shape_is_512(c->shape)) {
+        hipLaunchKernelGGL(k_spectra_512, dim3(1), dim3(64), 0, st, d_s1.as<uint32_t>(), d_spec.as<cd>(), c->tw.as<cd>(), 1);
+        hipLaunchKernelGGL((k_keygen_bsk_512<18>), dim3(P.n), dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(),
+                           d_spec.as<cd>(), d_s0.as<uint32_t>(), alpha_lv1, seed);
     } else {
         hipLaunchKernelGGL(k_keygen_s1_spectrum_2048, dim3(1), dim3(64), 0, st, d_s1.as<uint32_t>(), d_spec.as<cd>(), c->tw.as<cd>());
         hipLaunchKernelGGL((k_keygen_bsk_2048<22>), dim3(P.n * 2), dim3(64), 0, st, c->bsk.as<cd>(), c->tw.as<cd>(),
@@ -660,6 +688,9 @@ int tfhe_to_fourier_batch(tfhe_ctx *c, const uint32_t *polys, double *spectra, i
     if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_to_fourier, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(), c->s_t1.as<double>(),
                            c->tw.as<cd>());
+    else if (shape_is_512(c->shape))
+        hipLaunchKernelGGL(k_to_fourier_512, dim3((P + 1) / 2), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(),
+                           c->s_t1.as<double>(), c->tw.as<cd>(), P);
     else
         hipLaunchKernelGGL(k_to_fourier_2048, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(),
                            c->s_t1.as<double>(), c->tw.as<cd>());
@@ -682,6 +713,9 @@ int tfhe_to_poly_batch(tfhe_ctx *c, const double *spectra, uint32_t *polys, int 
     if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_to_poly, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
                            c->tw.as<cd>());
+    else if (shape_is_512(c->shape))
+        hipLaunchKernelGGL(k_to_poly_512, dim3((P + 1) / 2), dim3(64), 0, c->stream, c->s_t1.as<double>(),
+                           c->s_t0.as<uint32_t>(), c->tw.as<cd>(), P);
     else
         hipLaunchKernelGGL(k_to_poly_2048, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),
                            c->tw.as<cd>());

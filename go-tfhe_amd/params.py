@@ -32,14 +32,14 @@ Security80Bit = Params(n=550, N=1024, Nbit=10, L=3, Bgbit=6, basebit=2, t=7)
 Security110Bit = Params(n=630, N=1024, Nbit=10, L=3, Bgbit=6, basebit=2, t=8)
 Security128Bit = Params(n=700, N=1024, Nbit=10, L=3, Bgbit=6, basebit=2, t=9)
 SecurityUint1 = Params(n=700, N=1024, Nbit=10, L=2, Bgbit=10, basebit=2, t=8)      # params.go:194-232
+SecurityUint2 = Params(n=687, N=512, Nbit=9, L=1, Bgbit=18, basebit=4, t=3)        # params.go:236-265 (run at rank 1, as the reference does)
 SecurityUint3 = Params(n=820, N=1024, Nbit=10, L=1, Bgbit=23, basebit=6, t=2)      # params.go:277-313
 SecurityUint4 = Params(n=820, N=2048, Nbit=11, L=1, Bgbit=22, basebit=5, t=3)      # params.go:318-354
 SecurityUint5 = Params(n=1071, N=2048, Nbit=11, L=1, Bgbit=22, basebit=6, t=3)     # params.go:362-398
 SecurityUint6 = Params(n=1071, N=2048, Nbit=11, L=1, Bgbit=22, basebit=6, t=3)     # params.go:403-439
 SecurityUint7 = Params(n=1160, N=2048, Nbit=11, L=1, Bgbit=22, basebit=7, t=3)     # params.go:444-480
 SecurityUint8 = Params(n=1160, N=2048, Nbit=11, L=1, Bgbit=22, basebit=7, t=3)     # params.go:485-521
-# Uint2 (N=512, params.go:236-272) has no kernel: the wave FFT needs N >= 1024.
 
-BY_NAME = {"80": Security80Bit, "110": Security110Bit, "128": Security128Bit, "uint1": SecurityUint1,
+BY_NAME = {"80": Security80Bit, "110": Security110Bit, "128": Security128Bit, "uint1": SecurityUint1, "uint2": SecurityUint2,
            "uint3": SecurityUint3, "uint4": SecurityUint4, "uint5": SecurityUint5, "uint6": SecurityUint6,
            "uint7": SecurityUint7, "uint8": SecurityUint8}

@@ -143,11 +143,12 @@ def test_pbs_full_uint5_batch512(oracle, pkg, keys_u5_full, ck_u5_full):
     assert oracle.decrypt_message(k.p, 32, k.s0, ref) == 5
 
 
-@pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint3", 8), ("uint4", 16)])
+@pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint2", 4), ("uint3", 8), ("uint4", 16)])
 def test_pbs_other_uint_sets(oracle, pkg, name, modulus):
     # The other Uint sets the reference tests (params/uint_params_test.go:24-27): Uint1 (N=1024, L=2,
-    # Bgbit=10), Uint3 (N=1024, L=1, Bgbit=23), Uint4 (N=2048, L=1, Bgbit=22, basebit=5), full LWE dimension,
-    # cloud key generated on the GPU.  All three sit in the fp64 tolerance regime (values >= 2^52).
+    # Bgbit=10), Uint2 (N=512, L=1, Bgbit=18, basebit=4), Uint3 (N=1024, L=1, Bgbit=23), Uint4 (N=2048, L=1,
+    # Bgbit=22, basebit=5), full LWE dimension, cloud key generated on the GPU.  All sit in the fp64
+    # tolerance regime (values >= 2^52).
     p = oracle.params(name)
     rng = oracle.rng(0x7F4E0008)
     s0, s1 = oracle.keygen_secret(p, rng)
