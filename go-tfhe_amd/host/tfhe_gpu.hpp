@@ -44,7 +44,14 @@ using Params = tfhe_params;
 inline Params Security80Bit() { return {550, 1024, 10, 3, 6, 2, 7}; }
 inline Params Security110Bit() { return {630, 1024, 10, 3, 6, 2, 8}; }
 inline Params Security128Bit() { return {700, 1024, 10, 3, 6, 2, 9}; }
-inline Params SecurityUint5() { return {1071, 2048, 11, 1, 22, 6, 3}; }
+inline Params SecurityUint1() { return {700, 1024, 10, 2, 10, 2, 8}; }     // params.go:194-232
+inline Params SecurityUint2() { return {687, 512, 9, 1, 18, 4, 3}; }       // params.go:236-265
+inline Params SecurityUint3() { return {820, 1024, 10, 1, 23, 6, 2}; }     // params.go:277-313
+inline Params SecurityUint4() { return {820, 2048, 11, 1, 22, 5, 3}; }     // params.go:318-354
+inline Params SecurityUint5() { return {1071, 2048, 11, 1, 22, 6, 3}; }    // params.go:362-398
+inline Params SecurityUint6() { return {1071, 2048, 11, 1, 22, 6, 3}; }    // params.go:403-439
+inline Params SecurityUint7() { return {1160, 2048, 11, 1, 22, 7, 3}; }    // params.go:444-480
+inline Params SecurityUint8() { return {1160, 2048, 11, 1, 22, 7, 3}; }    // params.go:485-521
 } // namespace params
 
 namespace tlwe {

@@ -44,7 +44,7 @@ extern "C" {
  * (params.go:47): parameters are explicit per context. */
 typedef struct {
     int32_t n;        /* TLWELv0.N                       */
-    int32_t N;        /* TRGSWLv1.N  (1024 or 2048)      */
+    int32_t N;        /* TRGSWLv1.N  (512, 1024 or 2048) */
     int32_t Nbit;     /* TRGSWLv1.NBIT                   */
     int32_t L;        /* TRGSWLv1.L                      */
     int32_t Bgbit;    /* TRGSWLv1.BGBIT                  */
@@ -69,8 +69,8 @@ int tfhe_device_count(int *count);
  * functions of the parameters (cloudkey.go:60-85: decomposition offset, gate test
  * vector).  Supported parameter shapes: N=1024 with (L,Bgbit) = (3,6) [80/110/128-bit],
  * (2,10) [Uint1], (1,23) [Uint3]; N=2048 with (1,22) [Uint4, Uint5, and the shapes of
- * Uint6-8]; any n < 1280, any key-switch (basebit, t) with N*t <= 9216.  Anything else
- * (e.g. Uint2's N=512) returns TFHE_E_INVALID. */
+ * Uint6-8]; N=512 with (1,18) [Uint2]; any n < 1280, any key-switch (basebit, t) with
+ * N*t <= 9216.  Anything else returns TFHE_E_INVALID. */
 int tfhe_ctx_create(const tfhe_params *params, int device_id, tfhe_ctx **out);
 int tfhe_ctx_destroy(tfhe_ctx *ctx);
 int tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);

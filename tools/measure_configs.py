@@ -55,4 +55,15 @@ o = torch.empty_like(cts)
 dt = timed(lambda: ck.ctx.bootstrap_batch_dev(cts, lut, o), 5)
 out["config4_pbs_uint5_x512"] = {"pbs": 512, "seconds": dt, "pbs_per_s": 512 / dt,
                                  "blind_rotate_ms": ck.ctx.last_kernel_ms(0), "keyswitch_ms": ck.ctx.last_kernel_ms(1)}
+ck.close()
+# ---- Uint2 (N=512, one wave per bootstrap): PBS at one co-resident launch (2048) and a quarter of it
+p = pkg.params.SecurityUint2
+ck = pkg.CloudKey(p, bsk_torus=rnd((p.n, 2 * p.L, 2, p.N)), ksk=rnd((p.ksk_rows, p.n + 1)))
+lut = torch.from_numpy(rnd((2, p.N)).view(np.int32)).cuda()
+for Bb in (512, 2048, 8192):
+    cts = torch.from_numpy(rnd((Bb, p.n + 1)).view(np.int32)).cuda()
+    o = torch.empty_like(cts)
+    dt = timed(lambda: ck.ctx.bootstrap_batch_dev(cts, lut, o), 5)
+    out[f"pbs_uint2_x{Bb}"] = {"pbs": Bb, "seconds": dt, "pbs_per_s": Bb / dt,
+                                "blind_rotate_ms": ck.ctx.last_kernel_ms(0), "keyswitch_ms": ck.ctx.last_kernel_ms(1)}
 print(json.dumps(out, indent=1))
