@@ -534,6 +534,98 @@ __global__ __launch_bounds__(192) void k_keyswitch_tiled(KeySwitchArgs A, int B)
     }
 }
 
+// Column-sliced variant for the larger key-switch bases (Uint sets: base 16 ... 128), where a tile of
+// whole rows does not fit LDS and T = 32 ciphertexts would use at most half of the base-1 candidate
+// rows.  One workgroup = 256 ciphertexts x 64 output columns x IC extracted coefficients.  For each
+// (i, j) the base-1 candidate rows' 64-column slice (<= 32 KB) is staged double-buffered in LDS next
+// to a zero row; each of the 4 waves walks its own 64 ciphertexts: lane = column, the ciphertext's
+// digit is wave-uniform (v_readlane of a per-lane digit word), so the read is one conflict-free
+// ds_read_b32 at a scalar-selected row.  Every key row slice crosses L2 once per 256 ciphertexts.
+// grid = (ceil(B/256), ceil((n+1)/64), N/IC); partial sums are combined by atomics into the output
+// k_ks_init prepared.  (keyswitch.go:10-37, trlwe_ops.go:10-21)
+template <int BB>
+__global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, int IC)
+{
+    constexpr int base = 1 << BB, C = 64;
+    constexpr int Q = (base - 1) * 16, R = (Q + 255) / 256;     // staged uint4 per step, per thread
+    __shared__ uint32_t rowbuf[2][base][C];                      // [buffer][digit][column]; digit 0 = zeros
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = A.N, t = A.t;
+    const int b0 = blockIdx.x * 256 + w * 64, c0 = blockIdx.y * C, i0 = blockIdx.z * IC;
+    const uint32_t prec = 1u << (32 - (1 + BB * t));
+    const int wshift = 32 - BB * t;
+    if (tid < C) rowbuf[0][0][tid] = rowbuf[1][0][tid] = 0u;
+    // this thread's staged quads: q = tid + 256 r -> candidate row k = q/16 + 1, quad column q%16
+    const uint4 *src[R];
+    uint4 *dst[R];
+    bool live[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int q = tid + 256 * r, k1 = q >> 4, qc = q & 15;
+        live[r] = q < Q && c0 + 4 * qc < A.n1p;
+        src[r] = reinterpret_cast<const uint4 *>(A.ksk + ((size_t)i0 * t * (base - 1) + k1) * A.n1p + c0) + qc;
+        dst[r] = reinterpret_cast<uint4 *>(&rowbuf[0][(q < Q ? k1 : 0) + 1][0]) + qc;
+    }
+    const size_t pair_stride = (size_t)(base - 1) * A.n1p / 4;   // uint4 per (i, j) pair
+    constexpr int buf_quads = base * C / 4;
+    auto digit_word = [&](int i) -> uint32_t {
+        const int b = b0 + lane;
+        if (b >= B) return 0u;
+        const uint32_t *ta = A.trlwe + (size_t)b * 2 * N;
+        const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];                // trlwe_ops.go:13-19
+        return (ai + prec) >> wshift;                                     // all t digits, most significant first
+    };
+    uint4 g[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (live[r]) dst[r][0] = src[r][0];
+        else if (tid + 256 * r < Q) dst[r][0] = dst[r][buf_quads] = make_uint4(0, 0, 0, 0);   // columns past the row end
+    }
+    const int F = IC * t;
+#pragma unroll
+    for (int r = 0; r < R; r++) g[r] = live[r] ? src[r][(F > 1 ? 1 : 0) * pair_stride] : make_uint4(0, 0, 0, 0);
+    uint32_t acc[64];
+#pragma unroll
+    for (int b = 0; b < 64; b++) acc[b] = 0u;
+    uint32_t wm = digit_word(i0), wnext = IC > 1 ? digit_word(i0 + 1) : 0u;
+    __syncthreads();
+    int j = 0, ii = 0;
+    for (int f = 0; f < F; f++) {
+        const int cur = f & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (live[r]) dst[r][nxt * buf_quads] = g[r];
+        {
+            const int fn = f + 2 < F ? f + 2 : F - 1;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (live[r]) g[r] = src[r][(size_t)fn * pair_stride];
+        }
+        const int sh = BB * (t - 1 - j);
+        const uint32_t *tile = &rowbuf[cur][0][lane];
+#pragma unroll
+        for (int b = 0; b < 64; b++) {
+            const uint32_t k = ((uint32_t)__builtin_amdgcn_readlane((int)wm, b) >> sh) & (uint32_t)(base - 1);
+            acc[b] -= tile[k * C];
+        }
+        __syncthreads();
+        if (++j == t) {
+            j = 0; ii++;
+            wm = wnext;
+            wnext = ii + 1 < IC ? digit_word(i0 + ii + 1) : 0u;
+        }
+    }
+    const int col = c0 + lane;
+    if (col <= A.n) {
+#pragma unroll
+        for (int b = 0; b < 64; b++) {
+            if (b0 + b >= B) break;
+            if (acc[b]) atomicAdd(A.out + (size_t)(b0 + b) * (A.n + 1) + col, acc[b]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // FFT test seams, spectra in the reference FourierPoly layout.
 // ------------------------------------------------------------------------------------

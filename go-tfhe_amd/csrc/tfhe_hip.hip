@@ -223,6 +223,26 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         c->ev_valid[1] = !c->timing;
         return TFHE_OK;
     }
+    // larger bases (Uint sets), batches that fill at least one wave of ciphertexts: column-sliced tiles
+    if (c->P.basebit >= 4 && c->P.basebit <= 7 && B >= 64) {
+        const int ct_tiles = (B + 255) / 256, col_blocks = (c->P.n + 1 + 63) / 64;
+        int ranges = 1;                                   // coefficient ranges: enough workgroups for 4 per CU
+        while (ranges * 8 < c->P.N && ct_tiles * col_blocks * ranges < 4 * c->num_cus) ranges *= 2;
+        const int IC = c->P.N / ranges;
+        const size_t tot = (size_t)B * (c->P.n + 1);
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
+        const dim3 g(ct_tiles, col_blocks, ranges);
+        switch (c->P.basebit) {
+        case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, IC); break;
+        case 5: hipLaunchKernelGGL((k_keyswitch_wide<5>), g, dim3(256), 0, st, a, B, IC); break;
+        case 6: hipLaunchKernelGGL((k_keyswitch_wide<6>), g, dim3(256), 0, st, a, B, IC); break;
+        default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, IC); break;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(stop, st));
+        c->ev_valid[1] = !c->timing;
+        return TFHE_OK;
+    }
     // row indices fit 16 bits for the 2-bit key-switch base of the N=1024 sets (halves the LDS list)
     const bool small_idx = ksk_rows_packed(c->P) < 65535;
 #define KS_LAUNCH(CH)                                                                                   \

@@ -189,3 +189,29 @@ def test_uint7_shape_runs(oracle, pkg):
     out = ck.ctx.bootstrap_batch(cts, lut)
     assert [oracle.decrypt_message(p, 32, s0, np.ascontiguousarray(o)) for o in out] == [3, 12, 2]
     ck.close()
+
+
+@pytest.mark.parametrize("name,B", [("uint2", 64), ("uint2", 300), ("uint4", 70), ("uint5", 257), ("uint7", 65)])
+def test_wide_keyswitch_bit_exact(oracle, pkg, name, B):
+    # k_keyswitch_wide (bases 16 / 32 / 64 / 128, batch >= 64): integer-only, so bit-exact against the
+    # oracle (keyswitch.go:10-37) -- partial ciphertext tiles, a single partial column block (n = 48)
+    k = KeySet(oracle, name, 0x7F4E000B, n_override=48, torus=False)
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    trl = rand_u32(np.random.RandomState(37), (B, 2, k.p.N))
+    trl[1] = 0                                            # all digits zero except the rounding offset
+    trl[2] = 0xFFFFFFFF
+    got = ck.ctx.extract_keyswitch_batch(trl)
+    small = ck.ctx.extract_keyswitch_batch(trl[:5])      # the gather kernel on the same inputs
+    assert np.array_equal(got[:5], small)
+    for b in list(range(6)) + [63, B - 1]:
+        assert np.array_equal(got[b], oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[b]))), (name, b)
+    ck.close()
+
+
+def test_wide_keyswitch_full_dimension(oracle, keys_u5_full, ck_u5_full):
+    # n = 1071: 17 column blocks, the last one partial (1072 = 16*64 + 48)
+    k = keys_u5_full
+    trl = rand_u32(np.random.RandomState(38), (70, 2, 2048))
+    got = ck_u5_full.ctx.extract_keyswitch_batch(trl)
+    for b in (0, 1, 63, 64, 69):
+        assert np.array_equal(got[b], oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[b]))), b
