@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
     constexpr int N = 2048;
     constexpr double r = 0.70710678118654752440;
     __shared__ cd sc[4][kScratchSlots];
+    __shared__ cd dx[4][4 * 64];                  // digit-point hand-over between the two half-tree waves
     __shared__ uint32_t accL[2][N];
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
@@ -246,20 +247,37 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
     const cd *key = A.bsk + (size_t)p * 2 * 1024 + (size_t)h * 8 * 64 + lane;
     constexpr size_t kStep = (size_t)2 * 2 * 1024;
     const int wpart = ((1 - p) << 1) | h;               // same half of the other polynomial
+    const double sr = h ? -r : r;
     for (int i = 0; i < A.nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         const cd *kp = key + (size_t)i * kStep;
-        cd y[8];
+        // Both half-trees need all 16 digit points of the polynomial (y_h[a] = x[a] +- rho*x[a+8]).  Wave h
+        // extracts the points of a in [4h, 4h+4) only, forms both combinations, keeps its own and hands the
+        // other half-tree's through LDS: half the decomposition work per wave for 4 slots each way.
+        cd keep[4];
 #pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const uint32_t d0 = diff_coeff_2048(accL[p], at, nullptr, 64 * a + lane) + A.offset;
-            const uint32_t d1 = diff_coeff_2048(accL[p], at, nullptr, 64 * a + lane + 1024) + A.offset;
-            const uint32_t d2 = diff_coeff_2048(accL[p], at, nullptr, 64 * (a + 8) + lane) + A.offset;
-            const uint32_t d3 = diff_coeff_2048(accL[p], at, nullptr, 64 * (a + 8) + lane + 1024) + A.offset;
+        for (int q = 0; q < 4; q++) {
+            const int j = 256 * h + 64 * q + lane;
+            const uint32_t d0 = diff_coeff_2048(accL[p], at, nullptr, j) + A.offset;
+            const uint32_t d1 = diff_coeff_2048(accL[p], at, nullptr, j + 1024) + A.offset;
+            const uint32_t d2 = diff_coeff_2048(accL[p], at, nullptr, j + 512) + A.offset;
+            const uint32_t d3 = diff_coeff_2048(accL[p], at, nullptr, j + 512 + 1024) + A.offset;
             const cd lo = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
             const cd hi = cd{(double)((int)((d2 >> shift) & mask) - half), (double)((int)((d3 >> shift) & mask) - half)};
-            const cd rv = cd{(hi.re - hi.im) * r, (hi.re + hi.im) * r};          // rho * hi
-            y[a] = h ? lo - rv : lo + rv;
+            // sr = +-1/sqrt2 by half-tree: y_h[a] = lo + (+-rho)*hi is kept, lo - (+-rho)*hi goes to the other wave
+            // (written as FMAs with a uniform sign: a select between the two sums ends up in scratch memory)
+            const cd t = cd{hi.re - hi.im, hi.re + hi.im};
+            keep[q] = cd{fma(sr, t.re, lo.re), fma(sr, t.im, lo.im)};
+            dx[w][q * 64 + lane] = cd{fma(-sr, t.re, lo.re), fma(-sr, t.im, lo.im)};
+        }
+        __syncthreads();
+        cd y[8];
+        if (h == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { y[q] = keep[q]; y[4 + q] = dx[w ^ 1][q * 64 + lane]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { y[4 + q] = keep[q]; y[q] = dx[w ^ 1][q * 64 + lane]; }
         }
         fft512_forward(y, sc[w], table, tw, lane);
         const cd *kKeep = kp + (size_t)(p ? 1 : 0) * 1024;

@@ -289,12 +289,17 @@ __device__ __forceinline__ uint32_t round_to_torus_small(double v)
     return (uint32_t)__double2loint(v + 6755399441055744.0);
 }
 
-// General form for |v| up to 2^62 (Uint5: values reach ~2^58).
+// General form for |v| < 2^83 (the Uint sets reach ~2^58).  Adding 1.5*2^84 (ulp 2^32) and taking it
+// off again leaves q = v rounded to a multiple of 2^32, exactly; v - q is exact, |v - q| <= 2^31, and
+// differs from v by a multiple of 2^32, so the 2^52 trick on it gives round-to-nearest-even(v) mod 2^32
+// -- the same value as rint() followed by a floor-based reduction, in 4 additions.  The empty asm keeps
+// the compiler from folding (v + M) - M.
 __device__ __forceinline__ uint32_t round_to_torus_wide(double v)
 {
-    double r = rint(v);
-    double t = r - 4294967296.0 * floor(r * (1.0 / 4294967296.0));
-    return (uint32_t)t;
+    double q = v + 29014219670751100192948224.0;      // 1.5 * 2^84
+    asm volatile("" : "+v"(q));
+    q -= 29014219670751100192948224.0;
+    return round_to_torus_small(v - q);
 }
 
 } // namespace tfhe

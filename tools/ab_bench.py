@@ -11,18 +11,21 @@ import os, sys, json, numpy as np, torch
 sys.path.insert(0, %r)
 import __graft_entry__ as g
 pkg = g.load_package()
-p = pkg.params.Security128Bit
+B = int(sys.argv[1]); L = int(sys.argv[2]); pname = sys.argv[3]
+p = pkg.params.BY_NAME[pname]
 rs = np.random.RandomState(1)
 rnd = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
 ck = pkg.CloudKey(p, bsk_torus=rnd((p.n, 2*p.L, 2, p.N)), ksk=rnd((p.ksk_rows, p.n+1)))
-B = int(sys.argv[1]); L = int(sys.argv[2])
 a = torch.from_numpy(rnd((B, p.n+1)).view(np.int32)).cuda(); b = torch.from_numpy(rnd((B, p.n+1)).view(np.int32)).cuda()
 out = torch.empty_like(a)
-for _ in range(3): ck.ctx.gate_batch_dev("NAND", a, b, None, out)
+lut = torch.from_numpy(rnd((2, p.N)).view(np.int32)).cuda()
+# gate sets run NAND gates, Uint sets a LUT bootstrap (same two kernels)
+step = (lambda: ck.ctx.gate_batch_dev("NAND", a, b, None, out)) if pname in ("80", "110", "128") else (lambda: ck.ctx.bootstrap_batch_dev(a, lut, out))
+for _ in range(3): step()
 torch.cuda.synchronize()
 br, ks = [], []
 for _ in range(L):
-    ck.ctx.gate_batch_dev("NAND", a, b, None, out); torch.cuda.synchronize()
+    step(); torch.cuda.synchronize()
     br.append(ck.ctx.last_kernel_ms(0)); ks.append(ck.ctx.last_kernel_ms(1))
 print(json.dumps({"br": br, "ks": ks}))
 ''' % ROOT
@@ -32,6 +35,7 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--launches", type=int, default=12)
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--params", default="128", help="parameter set name (go-tfhe_amd/params.py BY_NAME)")
 args = ap.parse_args()
 res = {l: {"br": [], "ks": []} for l in args.libs}
 for r in range(args.rounds):
@@ -39,7 +43,7 @@ for r in range(args.rounds):
         env = dict(os.environ)
         if l != "default":
             env["TFHE_HIP_LIB"] = os.path.abspath(l)
-        out = subprocess.run([sys.executable, "-c", WORKER, str(args.batch), str(args.launches)], env=env,
+        out = subprocess.run([sys.executable, "-c", WORKER, str(args.batch), str(args.launches), args.params], env=env,
                              capture_output=True, text=True, cwd=ROOT)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])
