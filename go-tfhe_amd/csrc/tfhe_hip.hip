@@ -226,17 +226,17 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     // larger bases (Uint sets), batches that fill at least one wave of ciphertexts: column-sliced tiles
     if (c->P.basebit >= 4 && c->P.basebit <= 7 && B >= 64) {
         const int ct_tiles = (B + 255) / 256, col_blocks = (c->P.n + 1 + 63) / 64;
-        int ranges = 1;                                   // coefficient ranges: enough workgroups for 4 per CU
+        int ranges = 8;                                   // coefficient ranges: a multiple of 8 (XCD decode), enough workgroups for 4 per CU
         while (ranges * 8 < c->P.N && ct_tiles * col_blocks * ranges < 4 * c->num_cus) ranges *= 2;
         const int IC = c->P.N / ranges;
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
-        const dim3 g(ct_tiles, col_blocks, ranges);
+        const dim3 g((unsigned)(ct_tiles * col_blocks * ranges));
         switch (c->P.basebit) {
-        case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, IC); break;
-        case 5: hipLaunchKernelGGL((k_keyswitch_wide<5>), g, dim3(256), 0, st, a, B, IC); break;
-        case 6: hipLaunchKernelGGL((k_keyswitch_wide<6>), g, dim3(256), 0, st, a, B, IC); break;
-        default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, IC); break;
+        case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
+        case 5: hipLaunchKernelGGL((k_keyswitch_wide<5>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
+        case 6: hipLaunchKernelGGL((k_keyswitch_wide<6>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
+        default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(stop, st));
