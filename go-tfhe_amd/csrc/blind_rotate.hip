@@ -26,7 +26,19 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         if (a0.ops) a.ops = a0.ops + base;
         a.tv = a0.tv + (size_t)base * a0.tv_stride;
         a.out = a0.out + base * trl;
+        a.batch = cnt;
         const dim3 g(cnt);
+        // between one and two 2-wave workgroups per CU the hardware leaves a SIMD idle (see k_blind_rotate):
+        // pair the items into 4-wave workgroups instead
+        if (shape_is_1024(shape) && cnt > num_cus && cnt <= 2 * num_cus) {
+            const dim3 g2((cnt + 1) / 2);
+            switch (shape) {
+            case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6, 2>), g2, dim3(256), 0, st, a); break;
+            case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10, 2>), g2, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_blind_rotate<1, 23, 2>), g2, dim3(256), 0, st, a); break;
+            }
+            continue;
+        }
         switch (shape) {
         case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6>), g, dim3(128), 0, st, a); break;
         case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10>), g, dim3(128), 0, st, a); break;

@@ -76,6 +76,7 @@ struct BlindRotateArgs {
     uint32_t *out;          // [B][2][N]
     int n, nsteps, Nbit;
     uint32_t offset;        // decomposition offset (cloudkey.go:60-71)
+    int batch;              // items in this launch (only read by kernels that put several items in a workgroup)
 };
 
 constexpr int kMaxLweDim = 1280;      // Uint7/8 use n = 1160 (params.go:444-510)
@@ -196,21 +197,29 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     }
 }
 
-template <int L, int BGBIT>
-__global__ __launch_bounds__(128, 2) void k_blind_rotate(BlindRotateArgs A)
+// ITEMS = 2 puts two bootstraps (four waves) in one workgroup.  The hardware places the waves of ONE
+// workgroup on distinct SIMDs but not those of two co-resident 2-wave workgroups (tools/ubench_placement.hip:
+// two workgroups per CU land as [2 0 1 1] waves per SIMD, one SIMD idle), so launches of 1..2 workgroups per
+// CU use this form: one 4-wave workgroup per CU = [1 1 1 1].  The two items only share the barriers.
+template <int L, int BGBIT, int ITEMS = 1>
+__global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs A)
 {
     constexpr int N = 1024;
-    __shared__ cd sc[2][kScratchSlots];
-    __shared__ uint32_t accL[2][N];
-    __shared__ uint16_t abarL[kMaxLweDim];
-    __shared__ int btL;
-#ifdef TFHE_TW_LDS   // experiment: measured +3 % slower (spills, extra LDS reads) than rebuilding the powers
-    __shared__ cd twL[2 * 4 * 64];
-#endif
+    __shared__ cd scAll[ITEMS][2][kScratchSlots];
+    __shared__ uint32_t accAll[ITEMS][2][N];
+    __shared__ uint16_t abarAll[ITEMS][kMaxLweDim];
+    __shared__ int btAll[ITEMS];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int item = blockIdx.x;
+    const int lane = threadIdx.x & 63, tid = threadIdx.x & 127;              // tid: thread within the item's wave pair
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int p = w & 1, grp = ITEMS > 1 ? w >> 1 : 0;
+    cd (&sc)[2][kScratchSlots] = scAll[grp];
+    uint32_t (&accL)[2][N] = accAll[grp];
+    uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
+    int &btL = btAll[grp];
+    int item = blockIdx.x * ITEMS + grp;
+    const bool live = ITEMS == 1 || item < A.batch;        // odd batch: the idle pair recomputes the last item, stores nothing
+    if (!live) item = A.batch - 1;
     const int n = A.n;
 
     // ---- gate linear prep + mod-switch (gates_helper.go:10-63, evaluator.go:116,122)
@@ -234,10 +243,6 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BlindRotateArgs A)
     }
     LaneTwiddles tw;
     load_lane_twiddles(tw, A.tw, lane);
-#ifdef TFHE_TW_LDS   // experiment: measured +3 % slower (spills, extra LDS reads) than rebuilding the powers
-    fill_twiddle_lds(twL, A.tw, tid, 128);
-    use_twiddle_lds(tw, twL, lane);
-#endif
     __syncthreads();
 
     // ---- acc = X^bt * testvec  (evaluator.go:117-118, buffer_methods.go:133-164)
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(128, 2) void k_blind_rotate(BlindRotateArgs A)
         wave_lds_order();
     }
 
+    if (!live) return;
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) out[64 * q + lane] = accL[p][64 * q + lane];

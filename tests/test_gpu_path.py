@@ -265,3 +265,23 @@ def test_batch_larger_than_one_launch_with_per_item_testvec(oracle, keys_small, 
     out = ck_small.ctx.bootstrap_batch(cts, tvs)
     for b in (5, 1024, B - 1):
         assert np.array_equal(out[b], oracle.bootstrap(k.p, k.bsk, k.ksk, cts[b], tvs[b])), b
+
+
+@pytest.mark.parametrize("B", [257, 301, 512])
+def test_paired_workgroup_launch_bit_exact(oracle, keys_small, ck_small, pkg, B):
+    # 256 < B <= 512 is launched as 4-wave workgroups holding two bootstraps each (k_blind_rotate<.., 2>);
+    # an odd B leaves one wave pair idle in the last workgroup.  Per-item test vectors, per-item gate ops.
+    k = keys_small
+    rs = np.random.RandomState(25 + B)
+    cts = rand_u32(rs, (B, k.p.n + 1))
+    tvs = rand_u32(rs, (B, 2, 1024))
+    got = ck_small.ctx.blind_rotate_batch(cts, tvs)
+    for b in (0, 1, 2, 255, 256, B - 2, B - 1):
+        assert np.array_equal(got[b], oracle.blind_rotate(k.p, k.bsk, cts[b], tvs[b])), b
+    a, c = rand_u32(rs, (B, k.p.n + 1)), rand_u32(rs, (B, k.p.n + 1))
+    names = np.array(["NAND", "XOR", "ORNY", "AND"])[rs.randint(0, 4, B)]
+    ops = np.array([pkg.OPS[x] for x in names], np.uint8)
+    out = ck_small.ctx.gate_batch(ops, a, c)
+    sample = [0, 1, 256, B - 1]
+    ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops[sample], np.ascontiguousarray(a[sample]), np.ascontiguousarray(c[sample]))
+    assert np.array_equal(out[sample], ref)
