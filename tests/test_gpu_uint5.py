@@ -215,3 +215,25 @@ def test_wide_keyswitch_full_dimension(oracle, keys_u5_full, ck_u5_full):
     got = ck_u5_full.ctx.extract_keyswitch_batch(trl)
     for b in (0, 1, 63, 64, 69):
         assert np.array_equal(got[b], oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[b]))), b
+
+
+@pytest.mark.parametrize("name,B", [("uint5", 63), ("uint5", 64), ("uint5", 256), ("uint5", 513),
+                                    ("uint2", 63), ("uint2", 65), ("uint2", 2047), ("uint2", 2049)])
+def test_dispatch_boundaries_uint_shapes(oracle, pkg, name, B):
+    # gather / wide key switch (64), full launch (512 at N=2048, 2048 at N=512) and chunking: key switch
+    # bit-exact, PBS decrypts correctly for every item
+    modulus = {"uint5": 32, "uint2": 4}[name]
+    k = KeySet(oracle, name, 0x7F4E000C, n_override=40, torus=False)
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    rs = np.random.RandomState(2000 + B)
+    trl = rand_u32(rs, (B, 2, k.p.N))
+    got = ck.ctx.extract_keyswitch_batch(trl)
+    for b in sorted(set([0, B // 2, B - 1])):
+        assert np.array_equal(got[b], oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[b]))), (name, B, b)
+    msgs = rs.randint(0, modulus, B)
+    lut = oracle.lut_generate(k.p, [(3 * x + 1) % modulus for x in range(modulus)])
+    base = np.stack([oracle.encrypt_message(k.p, k.rng, m, modulus, k.s0) for m in range(modulus)])
+    out = ck.ctx.bootstrap_batch(base[msgs], lut)
+    dec = np.array([oracle.decrypt_message(k.p, modulus, k.s0, np.ascontiguousarray(o)) for o in out])
+    assert np.array_equal(dec, (3 * msgs + 1) % modulus), (name, B)
+    ck.close()
