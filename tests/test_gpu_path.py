@@ -3,7 +3,7 @@ Integer torus outputs are compared BIT-EXACT with the oracle (and the exact-inte
 import numpy as np
 import pytest
 
-from conftest import rand_u32
+from conftest import gpu_params, rand_u32
 
 pytestmark = pytest.mark.gpu
 
@@ -305,3 +305,36 @@ def test_dispatch_boundaries_gate_shape(oracle, keys_small, ck_small, pkg, B):
     uni = ck_small.ctx.gate_batch("NAND", a, b)
     sel = np.where(names == "NAND")[0]
     assert np.array_equal(uni[sel], out[sel])
+
+
+def test_concurrent_host_threads(oracle, keys_small, ck_small, pkg):
+    # A Go shim calls from many goroutines (the reference fans batches out over goroutines, trgsw.go:234-252).
+    # ctypes drops the GIL, so these threads really overlap: four on one shared context (serialised by its
+    # mutex), two on a second context of the same device.  Every result equals the single-threaded one.
+    import threading
+    k = keys_small
+    ck2 = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    rs = np.random.RandomState(77)
+    jobs = []
+    for t in range(6):
+        B = [40, 300, 7, 129, 64, 33][t]
+        jobs.append((ck_small if t < 4 else ck2, ["NAND", "XOR", "OR", "AND", "NOR", "XNOR"][t],
+                     rand_u32(rs, (B, k.p.n + 1)), rand_u32(rs, (B, k.p.n + 1))))
+    want = [ck.ctx.gate_batch(op, a, b).copy() for ck, op, a, b in jobs]
+    got, errs = [None] * len(jobs), []
+
+    def run(i):
+        try:
+            ck, op, a, b = jobs[i]
+            for _ in range(3):
+                got[i] = ck.ctx.gate_batch(op, a, b).copy()
+        except Exception as e:          # noqa: BLE001 - surfaced below
+            errs.append((i, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(len(jobs))]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errs, errs
+    for i in range(len(jobs)):
+        assert np.array_equal(got[i], want[i]), i
+    ck2.close()
