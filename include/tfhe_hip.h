@@ -19,6 +19,9 @@
  *     default stream, as for any hipStream_t) and only enqueue work on that stream, ordered
  *     with the caller's other work there; the others take HOST pointers, run on the
  *     context's private stream and return after the result is in the output buffer.
+ *     "_dev" calls of one context share its intermediate TRLWE buffer: enqueue them on ONE
+ *     stream at a time (stream order keeps them correct); for independent streams use one
+ *     context per stream.  Host-pointer calls of one context are serialised by a mutex.
  *   - all ciphertext words are uint32 torus values (params.Torus, params.go:27);
  *     an LWE sample is n+1 words with the body LAST (tlwe.go:11-33); a TRLWE sample is
  *     [2][N] words, A then B (trlwe.go:13-16).
