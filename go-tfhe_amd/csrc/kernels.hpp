@@ -461,14 +461,22 @@ static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *_
 }
 
 template <int T, int IC>
-__global__ __launch_bounds__(192) void k_keyswitch_tiled(KeySwitchArgs A, int B)
+__global__ __launch_bounds__(192) void k_keyswitch_tiled(KeySwitchArgs A, int B, int ct_tiles)
 {
     constexpr int kRowQ = 192;                       // LDS row stride in uint4 (>= quads)
     __shared__ uint4 rowbuf[2][4][kRowQ];            // [buffer][digit 0..3][quad]; digit 0 = zeros
     __shared__ uint32_t wds[IC][T];
     const int tid = threadIdx.x;
     const int N = A.N, t = A.t, bb = A.basebit;      // base = 4 => bb = 2
-    const int b0 = blockIdx.x * T, i0 = blockIdx.y * IC;
+    // 1-D grid of ct_tiles * N/IC workgroups; XCD-aware decode as in k_keyswitch_wide when N/IC is a
+    // multiple of 8: the ciphertext tiles of one coefficient range share an XCD's L2
+    int tx, ty;
+    {
+        const int id = blockIdx.x, ranges = N / IC;
+        if ((ranges & 7) == 0) { const int slot = id >> 3; tx = slot % ct_tiles; ty = (slot / ct_tiles) * 8 + (id & 7); }
+        else { tx = id % ct_tiles; ty = id / ct_tiles; }
+    }
+    const int b0 = tx * T, i0 = ty * IC;
     const uint32_t prec = 1u << (32 - (1 + bb * t));
     const int wshift = 32 - bb * t;
     for (int idx = tid; idx < IC * T; idx += 192) {

@@ -217,7 +217,8 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     if (c->P.basebit == 2 && c->n1p <= 768 && c->P.N % kIC == 0 && B >= kT) {
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
-        hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((B + kT - 1) / kT, c->P.N / kIC), dim3(192), 0, st, a, B);
+        const int ct_tiles = (B + kT - 1) / kT;
+        hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((unsigned)(ct_tiles * (c->P.N / kIC))), dim3(192), 0, st, a, B, ct_tiles);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(stop, st));
         c->ev_valid[1] = !c->timing;
