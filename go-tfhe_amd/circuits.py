@@ -31,7 +31,8 @@ def ripple_carry_adder(bits):
     lvl = []
     for i in range(bits):
         lvl.append(("XOR", a(i), b(i), None, s(0) if i == 0 else x[i]))
-        lvl.append(("AND", a(i), b(i), None, g[i]))
+        # a 1-bit adder's carry-out IS a_0 AND b_0: route it to the carry wire directly
+        lvl.append(("AND", a(i), b(i), None, 3 * bits if bits == 1 else g[i]))
     levels.append(lvl)
     carry = g[0]
     for i in range(1, bits):
@@ -51,6 +52,47 @@ def count_gates(levels):
 
 def count_bootstraps(levels):
     return sum(3 if g[0] == "MUX" else 1 for l in levels for g in l)
+
+
+def balance_levels(levels, width):
+    """Re-level a circuit WITHOUT lengthening its critical path so that levels are at most `width`
+    bootstraps wide wherever slack allows.  Every gate keeps a level between its earliest (all
+    producers done) and latest (no consumer delayed) position; each level first takes the gates
+    that must run now, then fills up to `width` with the ready gates of least slack.  One launch
+    costs a fixed ~2.4 ms of blind-rotate latency plus ~1.1 ms per 256 bootstraps up to one full
+    launch, so the cheapest schedule is the one with the fewest launches: a ripple-carry adder's
+    first level (all a_i XOR b_i, a_i AND b_i at once: four launches for 256 circuits) is spread
+    under the narrow carry-chain levels instead.  Wires are single-assignment, so any topological
+    levelling computes bit-identical results."""
+    gates = [g for lvl in levels for g in lvl]
+    D = len(levels)
+    producer = {g[4]: i for i, g in enumerate(gates)}
+    deps = [[producer[w] for w in (g[1], g[2], g[3]) if w is not None and w in producer] for g in gates]
+    users = [[] for _ in gates]
+    for i, d in enumerate(deps):
+        for j in d:
+            users[j].append(i)
+    alap = [D - 1] * len(gates)
+    for i in reversed(range(len(gates))):           # the given order is topological
+        for u in users[i]:
+            alap[i] = min(alap[i], alap[u] - 1)
+    weight = [3 if g[0] == "MUX" else 1 for g in gates]
+    done_at = [None] * len(gates)
+    out = []
+    pending = set(range(len(gates)))
+    for l in range(D):
+        ready = sorted((i for i in pending if all(done_at[j] is not None and done_at[j] < l for j in deps[i])),
+                       key=lambda i: (alap[i], i))
+        lvl, used = [], 0
+        for i in ready:
+            if alap[i] <= l or used + weight[i] <= width:
+                lvl.append(i); used += weight[i]
+        for i in lvl:
+            done_at[i] = l
+            pending.discard(i)
+        out.append([gates[i] for i in lvl])
+    assert not pending, "balance_levels: unschedulable gates (input order not topological?)"
+    return [lvl for lvl in out if lvl]
 
 
 class CircuitExecutor:
@@ -74,13 +116,14 @@ class CircuitExecutor:
             out = torch.tensor([g[4] for g in lvl], device=dev)
             uniform = lvl[0][0] if len(set(g[0] for g in lvl)) == 1 else None
             self._plan.append((ops, uniform, i0, i1, i2, out))
+        self._op_cache = {}                      # (level, C) -> per-item op codes on the device
 
     def run(self, wires, stream=None):
         """wires: int32 tensor [n_wires][C][n+1] with the input wires filled; updated in place."""
         torch = self.torch
         C = wires.shape[1]
         stream = stream or torch.cuda.current_stream()
-        for ops, uniform, i0, i1, i2, out in self._plan:
+        for li, (ops, uniform, i0, i1, i2, out) in enumerate(self._plan):
             G = i0.shape[0]
             a = wires.index_select(0, i0).reshape(G * C, self.n1)
             b = wires.index_select(0, i1).reshape(G * C, self.n1)
@@ -89,7 +132,9 @@ class CircuitExecutor:
             if uniform is not None:
                 self.ctx.gate_batch_dev(uniform, a, b, c, res, stream)
             else:
-                op_t = torch.from_numpy(np.repeat(ops, C)).to(a.device)
+                op_t = self._op_cache.get((li, C))
+                if op_t is None:
+                    op_t = self._op_cache[(li, C)] = torch.from_numpy(np.repeat(ops, C)).to(a.device)
                 self.ctx.gate_batch_dev(op_t, a, b, c, res, stream)
             wires.index_copy_(0, out, res.reshape(G, C, self.n1))
         return wires

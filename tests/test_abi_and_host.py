@@ -58,3 +58,27 @@ def test_shard_bounds_cover_batch(pkg):
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert sum(shard_sizes(total, world)) == total
+
+
+def test_balance_levels_keeps_depth_and_dependencies():
+    # host-side scheduler of go-tfhe_amd/circuits.py: any width gives a valid topological levelling of the
+    # same gates with the same critical-path length; levels respect the width wherever slack allows
+    import __graft_entry__ as graft
+    graft.load_package()
+    from go_tfhe_amd.circuits import ripple_carry_adder, balance_levels, count_gates
+    for bits in (1, 2, 8, 16):
+        levels, n_wires, sums, cout = ripple_carry_adder(bits)
+        flat = sorted(g for l in levels for g in l)
+        for width in (1, 2, 4, 100):
+            bal = balance_levels(levels, width)
+            assert len(bal) == len(levels)
+            assert sorted(g for l in bal for g in l) == flat
+            have = set(range(2 * bits))
+            for lvl in bal:
+                for (op, x, y, z, out) in lvl:
+                    assert x in have and y in have and (z is None or z in have)
+                have |= {g[4] for g in lvl}
+            assert all(w in have for w in sums + [cout])
+        assert [len(l) for l in balance_levels(levels, 10**6)][0] == 2 * bits       # no limit: the ASAP levelling
+    lv8 = balance_levels(ripple_carry_adder(8)[0], 4)
+    assert max(len(l) for l in lv8) <= 4

@@ -42,6 +42,15 @@ def test_adder_8bit_x256_128bit(oracle, keys128, ck128, pkg):
     carry = k.dec(res[cout]).astype(np.int64)
     assert np.array_equal(got, (av + bv) % 256)
     assert np.array_equal(carry, (av + bv) >> 8)
+    # the slack-balanced schedule (balance_levels: at most one full launch per level, same depth) computes
+    # bit-identical ciphertexts on every wire
+    from go_tfhe_amd.circuits import balance_levels
+    bal = balance_levels(levels, 1024 // C)
+    assert len(bal) == len(levels) and count_gates(bal) == count_gates(levels) and max(len(l) for l in bal) <= 4
+    wt2 = torch.from_numpy(wires.view(np.int32)).cuda()
+    CircuitExecutor(ck128.ctx, bal, n_wires).run(wt2)
+    torch.cuda.synchronize()
+    assert torch.equal(wt2, wt)
     # one circuit re-done gate by gate on the oracle: identical ciphertexts on every wire it wrote
     c0 = 17
     ow = {w: wires[w, c0] for w in range(2 * bits)}

@@ -31,7 +31,14 @@ ex = CircuitExecutor(ck.ctx, levels, nw)
 dt = timed(lambda: ex.run(wires), 5)
 G = count_gates(levels) * 256
 out["config3_adder8_x256"] = {"gates": G, "levels": len(levels), "seconds": dt, "gates_per_s": G / dt,
-                              "adds_per_s": 256 / dt}
+                              "adds_per_s": 256 / dt, "schedule": "ASAP levels (4096-gate first level)"}
+from go_tfhe_amd.circuits import balance_levels
+bal = balance_levels(levels, 1024 // 256)
+exb = CircuitExecutor(ck.ctx, bal, nw)
+dt = timed(lambda: exb.run(wires), 5)
+out["config3_adder8_x256_balanced"] = {"gates": G, "levels": len(bal), "widths": [len(l) for l in bal], "seconds": dt,
+                                       "gates_per_s": G / dt, "adds_per_s": 256 / dt,
+                                       "schedule": "balance_levels(width = 1024 / circuits)"}
 # config 5 (one-GPU slice): mixed AND/OR/XOR/MUX stream, 65536 gates
 B = 65536
 ops = torch.from_numpy(np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, B)]).cuda()
