@@ -212,13 +212,13 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
 
     const int lane = threadIdx.x & 63, tid = threadIdx.x & 127;              // tid: thread within the item's wave pair
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int p = w & 1, grp = ITEMS > 1 ? w >> 1 : 0;
+    const int p = w & 1, grp = ITEMS > 1 ? w >> 1 : 0;       // grp < ITEMS
     cd (&sc)[2][kScratchSlots] = scAll[grp];
     uint32_t (&accL)[2][N] = accAll[grp];
     uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
     int &btL = btAll[grp];
     int item = blockIdx.x * ITEMS + grp;
-    const bool live = ITEMS == 1 || item < A.batch;        // odd batch: the idle pair recomputes the last item, stores nothing
+    const bool live = ITEMS == 1 || item < A.batch;        // ragged batch: idle pairs recompute the last item, store nothing
     if (!live) item = A.batch - 1;
     const int n = A.n;
 

@@ -287,10 +287,11 @@ def test_paired_workgroup_launch_bit_exact(oracle, keys_small, ck_small, pkg, B)
     assert np.array_equal(out[sample], ref)
 
 
-@pytest.mark.parametrize("B", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 513, 767, 1023, 1025, 2049])
+@pytest.mark.parametrize("B", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 513, 767, 768, 769, 770, 1021, 1023, 1025, 2049])
 def test_dispatch_boundaries_gate_shape(oracle, keys_small, ck_small, pkg, B):
     # Every batch-size threshold of the launchers, both sides: gather / tiled key switch (32), one workgroup
-    # per CU (256), paired workgroups (257..512), three per CU, one full launch (1024), chunked launches.
+    # per CU (256), two items per workgroup (257..512), one (513..768), four (769..1024, ragged last workgroup
+    # with 1..3 idle wave pairs), chunked launches beyond 1024.
     # Whole gates (prep + blind rotate + extract + key switch) are bit-exact against the oracle.
     k = keys_small
     rs = np.random.RandomState(1000 + B)
