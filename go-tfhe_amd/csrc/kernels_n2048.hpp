@@ -192,20 +192,30 @@ __device__ __forceinline__ void external_product_core_2048(const uint32_t *accL,
 // the partner polynomial's share with wave (1-p, h), one 512-point inverse transform, then swap
 // halves with wave (p, 1-h) to undo the radix-2 level; wave h writes coefficient block
 // [512h, 512h+512) + {0, 1024}.  Four s_barriers per step.
-template <int BGBIT>
-__global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
+// ITEMS = 2: two bootstraps in one 8-wave workgroup = every resident wave of a CU (they share only the
+// barriers), as for k_blind_rotate<.., 4>.
+template <int BGBIT, int ITEMS = 1>
+__global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateArgs A)
 {
     constexpr int N = 2048;
     constexpr double r = 0.70710678118654752440;
-    __shared__ cd sc[4][kScratchSlots];
-    __shared__ cd dx[4][4 * 64];                  // digit-point hand-over between the two half-tree waves
-    __shared__ uint32_t accL[2][N];
-    __shared__ uint16_t abarL[kMaxLweDim];
-    __shared__ int btL;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ cd scAll[ITEMS][4][kScratchSlots];
+    __shared__ cd dxAll[ITEMS][4][4 * 64];        // digit-point hand-over between the two half-tree waves
+    __shared__ uint32_t accAll[ITEMS][2][N];
+    __shared__ uint16_t abarAll[ITEMS][kMaxLweDim];
+    __shared__ int btAll[ITEMS];
+    const int tid = threadIdx.x & 255, lane = tid & 63;                  // tid: thread within the item's four waves
+    const int wAll = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int w = wAll & 3, grp = ITEMS > 1 ? wAll >> 2 : 0;
     const int p = w >> 1, h = w & 1;
-    const int item = blockIdx.x;
+    cd (&sc)[4][kScratchSlots] = scAll[grp];
+    cd (&dx)[4][4 * 64] = dxAll[grp];
+    uint32_t (&accL)[2][N] = accAll[grp];
+    uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
+    int &btL = btAll[grp];
+    int item = blockIdx.x * ITEMS + grp;
+    const bool live = ITEMS == 1 || item < A.batch;
+    if (!live) item = A.batch - 1;                 // ragged batch: the idle group recomputes the last item, stores nothing
     const int n = A.n;
     {
         const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
@@ -312,6 +322,7 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
         }
         __syncthreads();
     }
+    if (!live) return;
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
