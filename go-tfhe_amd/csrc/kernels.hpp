@@ -8,7 +8,8 @@
 //                         only the bootstrapping key is streamed.
 //   k_external_product    evaluator.ExternalProductAssign (evaluator.go:50-81), same core.
 //   k_extract_keyswitch   trlwe.SampleExtractIndexAssign + trgsw.IdentityKeySwitchingAssign
-//                         (trlwe_ops.go:10-21, keyswitch.go:10-37).
+//                         (trlwe_ops.go:10-21, keyswitch.go:10-37), per-ciphertext gather (small batches);
+//   k_keyswitch_pair / k_keyswitch_wide   the same for batches, key rows shared by a tile of ciphertexts.
 //   k_bsk_from_fourier / k_bsk_from_torus / k_ksk_pack   key ingestion into device layouts.
 //   k_to_fourier / k_to_poly                              FFT test seams.
 #pragma once
@@ -442,15 +443,11 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
 }
 
 // ------------------------------------------------------------------------------------
-// Tiled key switch for base = 4 (the 80/110/128-bit sets): a workgroup owns T ciphertexts and a
-// range of IC extracted coefficients.  For every (i, j) the three candidate key rows are fetched
-// from global memory ONCE (coalesced 16 B per lane, two steps ahead) and staged in a double-
-// buffered LDS tile next to an all-zero row; each of the T ciphertexts then subtracts the row its
-// (wave-uniform) digit selects with one ds_read_b128 at a scalar-computed offset -- no branches,
-// and the k = 0 case is the zero row.  Compared with the per-ciphertext gather this moves each
-// key row through L2/MALL once per T ciphertexts instead of once per ciphertext that needs it.
-// Partial sums of the N/IC coefficient ranges are combined with 32-bit atomic adds into `out`,
-// which k_ks_init has set to (0, ..., 0, b)  (keyswitch.go:18-21).
+// Tiled key switches (k_keyswitch_pair for base 4, k_keyswitch_wide for the larger bases): a tile of
+// ciphertexts shares the candidate key rows of each (i, j), so a row crosses L2/MALL once per tile instead of
+// once per ciphertext that needs it (the per-ciphertext gather above).  Partial sums of the N/IC coefficient
+// ranges are combined with 32-bit atomic adds into `out`, which k_ks_init has set to (0, ..., 0, b)
+// (keyswitch.go:18-21).
 // ------------------------------------------------------------------------------------
 static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B)
 {
@@ -460,90 +457,88 @@ static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *_
     out[idx] = x == n ? trlwe[(size_t)b * 2 * N + N] : 0u;
 }
 
-template <int T, int IC>
-__global__ __launch_bounds__(192) void k_keyswitch_tiled(KeySwitchArgs A, int B, int ct_tiles)
+// Base-4 key switch, two (i, j) steps per LDS read.  One single-wave workgroup = T ciphertexts x 256 output
+// columns (4 per lane) x IC extracted coefficients.  LDS is used as a per-lane, dynamically indexed register
+// file: for each PAIR of consecutive steps the lane builds the 16 sums r[k1] + r'[k2] of its own column quad
+// (r[0] = r'[0] = 0; rows straight from L2, one pair ahead) and every ciphertext then needs ONE ds_read_b128
+// and one subtraction for two digits -- its two adjacent 2-bit digits are one 4-bit field of a 64-bit scalar
+// holding the 2t digits of a coefficient pair.  Lanes only ever read back what they wrote themselves, so there
+// is no barrier.  grid = ct_tiles * col_slices * N/IC workgroups, XCD-aware decode (the ciphertext tiles that
+// share key rows run on one XCD).  IC even.  (keyswitch.go:10-37, trlwe_ops.go:10-21; subtraction mod 2^32 is
+// associative and commutative, so pre-summing rows is exact.)
+template <int T>
+__global__ __launch_bounds__(64) void k_keyswitch_pair(KeySwitchArgs A, int B, int IC, int ct_tiles, int col_slices)
 {
-    constexpr int kRowQ = 192;                       // LDS row stride in uint4 (>= quads)
-    __shared__ uint4 rowbuf[2][4][kRowQ];            // [buffer][digit 0..3][quad]; digit 0 = zeros
-    __shared__ uint32_t wds[IC][T];
-    const int tid = threadIdx.x;
-    const int N = A.N, t = A.t, bb = A.basebit;      // base = 4 => bb = 2
-    // 1-D grid of ct_tiles * N/IC workgroups; XCD-aware decode as in k_keyswitch_wide when N/IC is a
-    // multiple of 8: the ciphertext tiles of one coefficient range share an XCD's L2
+    __shared__ uint4 comb[16][64];
+    const int lane = threadIdx.x;
+    const int N = A.N, t = A.t;                       // basebit = 2
     int tx, ty;
     {
-        const int id = blockIdx.x, ranges = N / IC;
-        if ((ranges & 7) == 0) { const int slot = id >> 3; tx = slot % ct_tiles; ty = (slot / ct_tiles) * 8 + (id & 7); }
+        const int id = blockIdx.x, ny = col_slices * (N / IC);
+        if ((ny & 7) == 0) { const int slot = id >> 3; tx = slot % ct_tiles; ty = (slot / ct_tiles) * 8 + (id & 7); }
         else { tx = id % ct_tiles; ty = id / ct_tiles; }
     }
-    const int b0 = tx * T, i0 = ty * IC;
-    const uint32_t prec = 1u << (32 - (1 + bb * t));
-    const int wshift = 32 - bb * t;
-    for (int idx = tid; idx < IC * T; idx += 192) {
-        const int ii = idx / T, b = idx - ii * T, i = i0 + ii;
-        uint32_t w = 0;
-        if (b0 + b < B) {
-            const uint32_t *ta = A.trlwe + (size_t)(b0 + b) * 2 * N;
-            const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];            // trlwe_ops.go:13-19
-            w = (ai + prec) >> wshift;                                     // all t digits, most significant first
-        }
-        wds[ii][b] = w;
-    }
-    rowbuf[0][0][tid] = make_uint4(0, 0, 0, 0);
-    rowbuf[1][0][tid] = make_uint4(0, 0, 0, 0);
+    const int b0 = tx * T, q0 = (ty % col_slices) * 64 + lane, i0 = (ty / col_slices) * IC;
     const int quads = A.n1p >> 2;
-    const bool active = tid < quads;
-    const int qd = active ? tid : 0;
+    const bool active = q0 < quads;
+    const uint32_t prec = 1u << (32 - (1 + 2 * t));
+    const int wshift = 32 - 2 * t;
+    auto digit_word = [&](int i) -> uint32_t {          // lane b < T holds ciphertext b0 + b
+        const int b = b0 + lane;
+        if (lane >= T || b >= B || i >= i0 + IC) return 0u;
+        const uint32_t *ta = A.trlwe + (size_t)b * 2 * N;
+        const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];                // trlwe_ops.go:13-19
+        return (ai + prec) >> wshift;                                     // t digits, most significant first
+    };
+    const uint4 *kbase = reinterpret_cast<const uint4 *>(A.ksk) + (size_t)i0 * t * 3 * quads + (active ? q0 : 0);
+    const size_t rowq = (size_t)quads;
+    const int F = IC * t;                                // steps of this workgroup (even)
+    uint4 n[6];
+    auto load_pair = [&](int f) {                        // rows of steps f and f+1
+        const uint4 *rp = kbase + (size_t)(f < F ? f : F - 2) * 3 * rowq;
+#pragma unroll
+        for (int r = 0; r < 6; r++) n[r] = rp[r * rowq];
+    };
+    load_pair(0);
+    comb[0][lane] = make_uint4(0, 0, 0, 0);
     uint4 acc[T];
 #pragma unroll
     for (int b = 0; b < T; b++) acc[b] = make_uint4(0, 0, 0, 0);
-    const uint4 *kbase = reinterpret_cast<const uint4 *>(A.ksk) + qd;
-    const size_t rowq = (size_t)quads;                                   // global row stride in uint4
-    const int F = IC * t;                                                // (i, j) pairs of this workgroup
-    const size_t f0 = (size_t)i0 * t;
-    auto row_ptr = [&](int f) { return kbase + ((f0 + f) * 3) * rowq; };
-    uint4 g1, g2, g3;                                                    // rows of pair f+1, in flight
-    {
-        const uint4 *rp = row_ptr(0);
-        rowbuf[0][1][tid] = rp[0]; rowbuf[0][2][tid] = rp[rowq]; rowbuf[0][3][tid] = rp[2 * rowq];
-        const uint4 *np = row_ptr(F > 1 ? 1 : 0);
-        g1 = np[0]; g2 = np[rowq]; g3 = np[2 * rowq];
-    }
-    __syncthreads();
-    uint32_t wd[T];
-    int j = 0, ii = 0;
-    for (int f = 0; f < F; f++) {
-        if (j == 0) {
+    auto add4 = [](uint4 x, uint4 y) { return make_uint4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); };
+    uint32_t wA = digit_word(i0), wB = digit_word(i0 + 1);
+    for (int cp = 0, f = 0; cp < IC / 2; cp++) {
+        // lane b: the 2t digits of ciphertext b for this coefficient pair, most significant first
+        const unsigned long long W = ((unsigned long long)wA << (2 * t)) | wB;
+        wA = digit_word(i0 + 2 * cp + 2);
+        wB = digit_word(i0 + 2 * cp + 3);
+        for (int P = 0; P < t; P++, f += 2) {
+            comb[1][lane] = n[3]; comb[2][lane] = n[4]; comb[3][lane] = n[5];
 #pragma unroll
-            for (int b = 0; b < T; b++) wd[b] = __builtin_amdgcn_readfirstlane(wds[ii][b]);
-        }
-        const int cur = f & 1, nxt = cur ^ 1;
-        // stage pair f+1 (loaded one iteration ago) and start loading pair f+2
-        rowbuf[nxt][1][tid] = g1; rowbuf[nxt][2][tid] = g2; rowbuf[nxt][3][tid] = g3;
-        {
-            const uint4 *np = row_ptr(f + 2 < F ? f + 2 : F - 1);
-            g1 = np[0]; g2 = np[rowq]; g3 = np[2 * rowq];
-        }
-        const int sh = bb * (t - 1 - j);
-        const uint4 *tile = &rowbuf[cur][0][tid];
+            for (int k1 = 1; k1 < 4; k1++) {
+                comb[4 * k1][lane] = n[k1 - 1];
 #pragma unroll
-        for (int b = 0; b < T; b++) {
-            const uint32_t k = (wd[b] >> sh) & 3u;
-            const uint4 r = tile[k * kRowQ];
-            acc[b].x -= r.x; acc[b].y -= r.y; acc[b].z -= r.z; acc[b].w -= r.w;
+                for (int k2 = 1; k2 < 4; k2++) comb[4 * k1 + k2][lane] = add4(n[k1 - 1], n[2 + k2]);
+            }
+            load_pair(f + 2);                            // lands under the T reads below
+            // per-lane byte offset of this ciphertext's table row for the two digits of steps f, f+1
+            const int sel = (int)((uint32_t)(W >> (4 * (t - 1 - P))) & 15u) * (int)sizeof(comb[0]);
+            const char *mine = reinterpret_cast<const char *>(&comb[0][lane]);
+#pragma unroll
+            for (int b = 0; b < T; b++) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(mine + __builtin_amdgcn_readlane(sel, b));
+                acc[b].x -= r.x; acc[b].y -= r.y; acc[b].z -= r.z; acc[b].w -= r.w;
+            }
         }
-        __syncthreads();
-        if (++j == t) { j = 0; ii++; }
     }
     if (active) {
 #pragma unroll
         for (int b = 0; b < T; b++) {
             if (b0 + b >= B) break;
-            uint32_t *o = A.out + (size_t)(b0 + b) * (A.n + 1) + 4 * qd;
+            uint32_t *o = A.out + (size_t)(b0 + b) * (A.n + 1) + 4 * q0;
             const uint32_t v[4] = {acc[b].x, acc[b].y, acc[b].z, acc[b].w};
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                if (4 * qd + c <= A.n && v[c]) atomicAdd(o + c, v[c]);
+                if (4 * q0 + c <= A.n && v[c]) atomicAdd(o + c, v[c]);
         }
     }
 }

@@ -211,14 +211,19 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
-    // base-4 sets: tiled kernel (key rows shared by 32 ciphertexts); needs a full row in 192 lanes
-    constexpr int kT = 32, kIC = 32;
-    // (IC = 16 / 64 / 128 measured 0.80 / 0.68 / 1.07 ms against 0.71 ms for 32 on 1024 ciphertexts)
-    if (c->P.basebit == 2 && c->n1p <= 768 && c->P.N % kIC == 0 && B >= kT) {
+    // base-4 sets (80/110/128-bit): tiles of 32 ciphertexts x 256 columns, two (i, j) steps per LDS read
+    constexpr int kT = 32;
+    if (c->P.basebit == 2 && B >= kT && c->P.N % 16 == 0) {
+        const int ct_tiles = (B + kT - 1) / kT, col_slices = ((c->n1p >> 2) + 63) / 64;
+        // coefficient ranges: a multiple of 8 (XCD decode), IC = N/ranges even and >= 8, about 1.5 single-wave
+        // workgroups per SIMD (IC = 64 at B = 1024: 0.50 ms; IC = 32: 0.55 ms)
+        int ranges = 8;
+        while (ranges * 16 <= c->P.N && ct_tiles * col_slices * ranges < 6 * c->num_cus) ranges *= 2;
+        const int IC = c->P.N / ranges;
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
-        const int ct_tiles = (B + kT - 1) / kT;
-        hipLaunchKernelGGL((k_keyswitch_tiled<kT, kIC>), dim3((unsigned)(ct_tiles * (c->P.N / kIC))), dim3(192), 0, st, a, B, ct_tiles);
+        hipLaunchKernelGGL((k_keyswitch_pair<kT>), dim3((unsigned)(ct_tiles * col_slices * ranges)), dim3(64), 0, st, a, B, IC,
+                           ct_tiles, col_slices);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(stop, st));
         c->ev_valid[1] = !c->timing;
