@@ -20,11 +20,15 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 rs = np.random.RandomState(0)
 A = rs.randint(0, 2, B); Bb = rs.randint(0, 2, B)
 a = o.encrypt_bools(p, rng, A, s0); b = o.encrypt_bools(p, rng, Bb, s0)
-for it in range(3):
+walls = []
+for it in range(10):
     t = time.time()
     out = ck.ctx.gate_batch("NAND", a, b)
     dt = time.time() - t
+    walls.append(dt)
     print(f"iter {it}: {dt*1e3:.1f} ms wall, BR kernel {ck.ctx.last_kernel_ms(0):.2f} ms, KS kernel {ck.ctx.last_kernel_ms(1):.2f} ms, {B/dt:.0f} gates/s", flush=True)
+med = sorted(walls)[len(walls) // 2]
+print(f"pageable host buffers: median {med*1e3:.2f} ms wall = {B/med:.0f} gates/s")
 dec = o.decrypt_bools(p, s0, out)
 print("correct:", int((dec == ~(A.astype(bool) & Bb.astype(bool))).sum()), "/", B)
 want, _ = o.gate_batch(p, bsk, ksk, "NAND", a[:4], b[:4])
@@ -32,9 +36,11 @@ print("bit-exact first 4:", np.array_equal(out[:4], want))
 # page-locked operands/outputs (tfhe_host_alloc): the fast path of the host-pointer ABI
 pa, pb, po = pkg.PinnedArray(a.shape), pkg.PinnedArray(b.shape), pkg.PinnedArray(a.shape)
 pa.array[...] = a; pb.array[...] = b
-for it in range(3):
+walls = []
+for it in range(10):
     t = time.time()
     ck.ctx.gate_batch("NAND", pa.array, pb.array, out=po.array)
-    dt = time.time() - t
-    print(f"pinned iter {it}: {dt*1e3:.1f} ms wall, {B/dt:.0f} gates/s", flush=True)
+    walls.append(time.time() - t)
+med = sorted(walls)[len(walls) // 2]
+print(f"page-locked host buffers (tfhe_host_alloc): median {med*1e3:.2f} ms wall = {B/med:.0f} gates/s", flush=True)
 print("pinned result identical:", np.array_equal(po.array, out))
