@@ -211,8 +211,9 @@ def main():
             "roofline": {"kernel": "k_blind_rotate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("k_blind_rotate"),
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": br_avg_ms, "launches": br_n,
-                         "note": "all 1024 workgroups stream the key in near lock-step, so it is served by L2/MALL: "
-                                 "algorithmic GB/s can exceed the HBM peak; the kernel is fp64-VALU/LDS bound",
+                         "note": "all 1024 bootstraps stream the same key, four per workgroup in step: each XCD's L2 fetches "
+                                 "it once (traffic = 8 x 68.8 MB), so algorithmic GB/s exceeds the HBM peak; the kernel "
+                                 "is fp64-VALU/LDS bound",
                          "fp64_tflops": fp64_flops_per_bootstrap(p) * BATCH / (br_avg_ms * 1e-3) / 1e12,
                          "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
             "kernels": {"k_blind_rotate_ms": br_avg_ms, "k_extract_keyswitch_ms": ks_avg_ms,
