@@ -6,9 +6,9 @@ fallback: importing works anywhere (so the CPU test tier can check the ABI), but
 context without a GPU, or with the library missing, raises.
 """
 from . import params  # noqa: F401
-from .params import (Params, Security80Bit, Security110Bit, Security128Bit, SecurityUint1, SecurityUint3,  # noqa: F401
-                     SecurityUint4, SecurityUint5, SecurityUint6, SecurityUint7, SecurityUint8)
+from .params import (Params, Security80Bit, Security110Bit, Security128Bit, SecurityUint1, SecurityUint2,  # noqa: F401
+                     SecurityUint3, SecurityUint4, SecurityUint5, SecurityUint6, SecurityUint7, SecurityUint8)
 from ._binding import (Context, PinnedArray, TfheError, OPS, library_path, load_library, exported_symbols,  # noqa: F401
                        declared_symbols)
 from .cloudkey import CloudKey  # noqa: F401
-from . import gates, evaluator  # noqa: F401
+from . import gates, evaluator, lut  # noqa: F401

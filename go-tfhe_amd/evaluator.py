@@ -31,11 +31,24 @@ class Evaluator:
         return self.ctx.bootstrap_batch(np.asarray(ct_in)[None], testvec)[0]
 
     # programmable_bootstrap.go:54-69,93-115 : the LUT is a TRLWE test vector [2][N]
+    # (a lut.LookUpTable or its [2][N] array)
     def BootstrapLUT(self, ct_in, lut):
-        return self.ctx.bootstrap_batch(np.asarray(ct_in)[None], lut)[0]
+        return self.ctx.bootstrap_batch(np.asarray(ct_in)[None], getattr(lut, "poly", lut))[0]
 
     def BootstrapLUTAssign(self, ct_in, lut, ct_out):
         ct_out[...] = self.BootstrapLUT(ct_in, lut)
+
+    # programmable_bootstrap.go:16-52 : build the table for f over [0, messageModulus), then bootstrap
+    def BootstrapFunc(self, ct_in, f, messageModulus):
+        from .lut import Generator
+        return self.BootstrapLUT(ct_in, Generator(self.ctx.params, messageModulus).GenLookUpTable(f))
+
+    def BootstrapFuncAssign(self, ct_in, f, messageModulus, ct_out):
+        ct_out[...] = self.BootstrapFunc(ct_in, f, messageModulus)
+
+    # one table, many ciphertexts in one launch (the batch form of BootstrapLUT)
+    def BatchBootstrapLUT(self, cts, lut):
+        return self.ctx.bootstrap_batch(cts, getattr(lut, "poly", lut))
 
     # batch forms (trgsw.go:234-252)
     def BatchBlindRotate(self, cts, testvec=None):

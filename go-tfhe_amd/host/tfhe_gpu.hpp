@@ -8,16 +8,20 @@
 //   tlwe::       TLWELv0 sample + linear ops        (tlwe/tlwe.go:11-33,76-134)
 //   trlwe::      TRLWELv1 sample                    (trlwe/trlwe.go:13-25)
 //   cloudkey::   CloudKey resident on one GPU       (cloudkey/cloudkey.go:16-31)
+//   lut::        LookUpTable, Encoder, Generator    (lut/lut.go:13-45, encoder.go:10-107, generator.go:10-173)
 //   evaluator::  Evaluator {ExternalProductAssign, BlindRotateAssign, BootstrapAssign, Bootstrap,
-//                BootstrapLUTAssign, Prepare*}      (evaluator/evaluator.go:50-157, gates_helper.go:10-63,
-//                                                    programmable_bootstrap.go:54-115)
+//                BootstrapLUT[Assign], BootstrapFunc[Assign], Prepare*}
+//                                                   (evaluator/evaluator.go:50-157, gates_helper.go:10-63,
+//                                                    programmable_bootstrap.go:16-115)
 //   gates::      NAND ... MUX, NOT, Copy, Constant, Batch*   (gates/gates.go:26-126,156-312)
 //
 // Header-only; link with -ltfhe_hip.  Everything that computes goes through include/tfhe_hip.h.
 #pragma once
 
 #include <array>
+#include <cmath>
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -138,6 +142,82 @@ inline std::vector<tlwe::TLWELv0> unflatten(const std::vector<uint32_t> &f, size
 }
 } // namespace detail
 
+namespace lut {
+// utils/utils.go:11-19
+inline params::Torus F64ToTorus(double d) { return (params::Torus)(int64_t)(std::fmod(d, 1.0) * 4294967296.0); }
+inline double TorusToF64(params::Torus t) { return (double)t / 4294967296.0; }
+
+// lut.go:13-45 : a TRLWE whose B polynomial holds the table (A = 0 for generated tables)
+struct LookUpTable {
+    trlwe::TRLWELv1 Poly;
+    explicit LookUpTable(int N) : Poly(N) {}
+    LookUpTable Copy() const { return *this; }
+    void CopyFrom(const LookUpTable &o) { Poly = o.Poly; }
+    void Clear() { std::fill(Poly.A.begin(), Poly.A.end(), 0u); std::fill(Poly.B.begin(), Poly.B.end(), 0u); }
+};
+
+// encoder.go:10-107 : message i of a modulus-m space sits at i * Scale, Scale = 1/(2m) by default
+struct Encoder {
+    int MessageModulus;
+    double Scale;
+    explicit Encoder(int messageModulus) : MessageModulus(messageModulus), Scale(1.0 / (2.0 * messageModulus)) {}
+    Encoder(int messageModulus, double scale) : MessageModulus(messageModulus), Scale(scale) {}
+    int wrap(long m) const { m %= MessageModulus; return (int)(m < 0 ? m + MessageModulus : m); }
+    params::Torus Encode(int message) const { return EncodeWithCustomScale(message, Scale); }
+    params::Torus EncodeWithCustomScale(int message, double scale) const { return F64ToTorus((double)wrap(message) * scale); }
+    int Decode(params::Torus v) const { return wrap((long)(TorusToF64(v) / Scale + 0.5)); }
+    bool DecodeBool(params::Torus v) const { return Decode(v) != 0; }
+};
+
+// generator.go:10-173 for one parameter set (LookUpTableSize = N; the reference has no extended tables either)
+class Generator {
+  public:
+    Encoder Enc;
+    int PolyDegree, LookUpTableSize;
+    Generator(const params::Params &p, int messageModulus) : Enc(messageModulus), PolyDegree(p.N), LookUpTableSize(p.N) {}
+    Generator(const params::Params &p, int messageModulus, double scale) : Enc(messageModulus, scale), PolyDegree(p.N), LookUpTableSize(p.N) {}
+
+    LookUpTable GenLookUpTable(const std::function<int(int)> &f) const
+    {
+        return fill(Enc.MessageModulus, [&](int x) { return Enc.Encode(f(x)); });
+    }
+    void GenLookUpTableAssign(const std::function<int(int)> &f, LookUpTable &out) const { out = GenLookUpTable(f); }
+    LookUpTable GenLookUpTableFull(const std::function<params::Torus(int)> &f) const { return fill(Enc.MessageModulus, f); }
+    LookUpTable GenLookUpTableCustom(const std::function<int(int)> &f, int messageModulus, double scale) const
+    {
+        const Encoder e(messageModulus, scale);
+        return fill(messageModulus, [&](int x) { return e.Encode(f(x)); });
+    }
+    // generator.go:159-168
+    int ModSwitch(params::Torus x) const
+    {
+        const long r = std::lround((double)x / 4294967296.0 * LookUpTableSize) % LookUpTableSize;
+        return (int)(r < 0 ? r + LookUpTableSize : r);
+    }
+
+  private:
+    static long divRound(long a, long b) { return (a + b / 2) / b; }       // generator.go:171-173
+    // Coefficient i of the table is the value of the message whose raw range contains (i + offset) mod N,
+    // offset = divRound(N, 2m); the coefficients that wrapped around are negated  (generator.go:62-93).
+    LookUpTable fill(int m, const std::function<params::Torus(int)> &value) const
+    {
+        const long N = LookUpTableSize, offset = divRound(N, 2L * m);
+        std::vector<params::Torus> val((size_t)m);
+        for (int x = 0; x < m; x++) val[(size_t)x] = value(x);
+        LookUpTable out((int)N);
+        int x = 0;
+        for (long k = 0; k < N; k++) {                           // k walks the raw positions, in rotated order
+            const long src = (k + offset) % N;
+            if (src == 0) x = 0;
+            while (x + 1 < m && src >= divRound((long)(x + 1) * N, m)) x++;
+            const params::Torus v = val[(size_t)x];
+            out.Poly.B[(size_t)k] = k >= N - offset ? 0u - v : v;
+        }
+        return out;
+    }
+};
+} // namespace lut
+
 namespace evaluator {
 // evaluator.go:14-35.  The bsk / ksk / decompositionOffset arguments of the Go methods are the
 // ones resident in the CloudKey; outputs are caller-owned (the *Assign style).
@@ -184,6 +264,16 @@ class Evaluator {
     // programmable_bootstrap.go:93-115 : the LUT is a TRLWE with A = 0, B = table
     void BootstrapLUTAssign(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 &lut, tlwe::TLWELv0 &ctOut) const { BootstrapAssign(ctIn, &lut, ctOut); }
     tlwe::TLWELv0 BootstrapLUT(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 &lut) const { return Bootstrap(ctIn, &lut); }
+    tlwe::TLWELv0 BootstrapLUT(const tlwe::TLWELv0 &ctIn, const lut::LookUpTable &t) const { return Bootstrap(ctIn, &t.Poly); }
+    // programmable_bootstrap.go:16-52 : table for f over [0, messageModulus), then bootstrap
+    tlwe::TLWELv0 BootstrapFunc(const tlwe::TLWELv0 &ctIn, const std::function<int(int)> &f, int messageModulus) const
+    {
+        return BootstrapLUT(ctIn, lut::Generator(ck_.P, messageModulus).GenLookUpTable(f));
+    }
+    void BootstrapFuncAssign(const tlwe::TLWELv0 &ctIn, const std::function<int(int)> &f, int messageModulus, tlwe::TLWELv0 &ctOut) const
+    {
+        ctOut = BootstrapFunc(ctIn, f, messageModulus);
+    }
     // batch forms (trgsw.go:234-252)
     std::vector<tlwe::TLWELv0> BatchBootstrap(const std::vector<tlwe::TLWELv0> &in, const trlwe::TRLWELv1 *testvec = nullptr) const
     {

@@ -1,6 +1,7 @@
 // C++ host-mirror test (runs on the GPU box): the reference's own gate tests re-expressed
 // against tfhe::gates / tfhe::evaluator (gates/gates_test.go:23-366, 369-480), with the CPU
 // oracle (test infrastructure) as key generator, encryptor/decryptor and bit-exact checker.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -93,6 +94,38 @@ int main()
     orc_gate_testvec(&op, tv.data());
     orc_blind_rotate(&op, fft, bsk.data(), prep.P.data(), tv.data(), -1, want.data());
     EXPECT(std::equal(acc.A.begin(), acc.A.end(), want.begin()) && std::equal(acc.B.begin(), acc.B.end(), want.begin() + op.N), "BlindRotateAssign");
+    // lut package + BootstrapFunc (lut_test.go:10-215, programmable_bootstrap_test.go:13-188)
+    {
+        lut::Encoder e4(4);
+        for (int i = 0; i < 4; i++) EXPECT(e4.Decode(e4.Encode(i)) == i, "Encoder(4) round trip %d", i);
+        EXPECT(e4.Encode(-1) == e4.Encode(3) && e4.Encode(4) == e4.Encode(0), "Encoder wrap-around");
+        EXPECT(lut::F64ToTorus(-0.125) == 0xE0000000u && lut::F64ToTorus(0.5) == 0x80000000u, "F64ToTorus known answers");
+        const int moduli[] = {2, 3, 4, 8};
+        for (int m : moduli) {
+            std::vector<int32_t> tab(m);
+            for (int x = 0; x < m; x++) tab[x] = (3 * x + 1) % m;
+            auto t = lut::Generator(p, m).GenLookUpTable([&](int x) { return tab[x]; });
+            std::vector<uint32_t> ref(2 * op.N);
+            orc_lut_generate(&op, tab.data(), m, ref.data());
+            EXPECT(std::equal(t.Poly.A.begin(), t.Poly.A.end(), ref.begin()) && std::equal(t.Poly.B.begin(), t.Poly.B.end(), ref.begin() + op.N),
+                   "Generator(%d) differs from the oracle table", m);
+        }
+        lut::Generator g2(p, 2);
+        EXPECT(g2.ModSwitch(0) == 0 && g2.ModSwitch(1u << 30) == op.N / 4 && g2.ModSwitch(1u << 31) == op.N / 2 && g2.ModSwitch(0xFFFFFFFFu) == 0, "ModSwitch");
+        int (*fs[3])(int) = {[](int x) { return x; }, [](int x) { return 1 - x; }, [](int) { return 1; }};
+        for (auto f : fs)
+            for (int m = 0; m < 2; m++) {
+                gates::Ciphertext ct(op.n);
+                orc_tlwe_encrypt_message(&op, &rng, m, 2, s0.data(), ct.P.data());
+                auto out = ev.BootstrapFunc(ct, f, 2);
+                EXPECT(orc_tlwe_decrypt_message(&op, 2, s0.data(), out.P.data()) == f(m), "BootstrapFunc decrypts wrong (m=%d)", m);
+                const int32_t tab[2] = {f(0), f(1)};
+                std::vector<uint32_t> tvf(2 * op.N), wantf(op.n + 1);
+                orc_lut_generate(&op, tab, 2, tvf.data());
+                orc_bootstrap(&op, fft, bsk.data(), ksk.data(), ct.P.data(), tvf.data(), wantf.data());
+                EXPECT(out.P == wantf, "BootstrapFunc differs from the oracle (m=%d)", m);
+            }
+    }
     // error behaviour: a Go panic is a thrown Panic
     bool threw = false;
     try { gates::Ciphertext bad(3); gates::NAND(bad, bad, ck); } catch (const Panic &) { threw = true; }

@@ -1,5 +1,6 @@
 """CPU tier: the C-ABI library loads and exports every declared symbol; host-side logic."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -82,3 +83,71 @@ def test_balance_levels_keeps_depth_and_dependencies():
         assert [len(l) for l in balance_levels(levels, 10**6)][0] == 2 * bits       # no limit: the ASAP levelling
     lv8 = balance_levels(ripple_carry_adder(8)[0], 4)
     assert max(len(l) for l in lv8) <= 4
+
+
+# ---- host mirror of the reference's lut package (go-tfhe_amd/lut.py) -------------------------------
+
+def _lut_mod():
+    import __graft_entry__ as graft
+    return graft.load_package().lut
+
+
+def test_lut_f64_to_torus_known_answers():
+    # utils/utils_test.go:15-20, the same vectors the oracle is pinned with
+    lut = _lut_mod()
+    for d, want in [(0.0, 0), (0.5, 1 << 31), (0.25, 1 << 30), (0.125, 1 << 29), (-0.125, 0xE0000000), (1.25, 1 << 30)]:
+        assert int(lut.f64_to_torus(d)) == want, d
+    assert lut.f64_to_torus(np.array([0.5, -0.125])).tolist() == [1 << 31, 0xE0000000]
+
+
+def test_lut_table_and_encoder_like_the_reference_tests():
+    lut = _lut_mod()
+    # lut_test.go:10-53 LookUpTable basic / copy
+    t = lut.LookUpTable(1024)
+    assert t.poly.shape == (2, 1024) and not t.poly.any()
+    t.B[0], t.A[0] = 42, 17
+    c = t.Copy()
+    assert c.B[0] == 42 and c.A[0] == 17
+    t.B[0] = 99
+    assert c.B[0] == 42
+    d = lut.LookUpTable(1024); d.CopyFrom(t)
+    assert d.B[0] == 99
+    d.Clear()
+    assert not d.poly.any()
+    # lut_test.go:55-83 binary encoder, :85-106 modulus 4 with wrap-around
+    e2 = lut.Encoder(2)
+    assert e2.Decode(e2.Encode(0)) == 0 and e2.Decode(e2.Encode(1)) == 1
+    assert e2.DecodeBool(e2.Encode(0)) == False and e2.DecodeBool(e2.Encode(1)) == True   # noqa: E712
+    e4 = lut.Encoder(4)
+    assert [e4.Decode(e4.Encode(i)) for i in range(4)] == [0, 1, 2, 3]
+    assert e4.Encode(-1) == e4.Encode(3) and e4.Encode(4) == e4.Encode(0)
+    assert int(e4.Encode(1)) == 1 << 29 and e4.Scale == 0.125                           # i / (2m) of the torus
+
+
+def test_lut_generator_equals_oracle_and_golden(oracle):
+    import __graft_entry__ as graft
+    pkg = graft.load_package()
+    lut = pkg.lut
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "lut_uint5_identity.npz"))["lut"]
+    g = lut.Generator(pkg.params.SecurityUint5, 32)
+    assert np.array_equal(g.GenLookUpTable(lambda x: x).poly, gold)
+    rs = np.random.RandomState(5)
+    for name, moduli in (("80", (2, 4)), ("128", (2, 3, 8)), ("uint2", (4,)), ("uint3", (8,)), ("uint4", (16, 5)),
+                         ("uint5", (32, 7, 64)), ("uint7", (32,))):
+        p = oracle.params(name)
+        for m in moduli:
+            table = [int(v) for v in rs.randint(0, m, m)]
+            got = lut.Generator(pkg.params.BY_NAME[name], m).GenLookUpTable(lambda x: table[x])
+            assert np.array_equal(got.poly, oracle.lut_generate(p, table)), (name, m)
+            assert not got.A.any()
+    # GenLookUpTableFull with the encoder's values and GenLookUpTableCustom with its scale are the same table
+    g8 = lut.Generator(pkg.params.SecurityUint3, 8)
+    f = lambda x: (2 * x) % 8                                                            # lut_test.go:150-161
+    ref = g8.GenLookUpTable(f).poly
+    assert np.array_equal(g8.GenLookUpTableCustom(f, 8, 1.0 / 16.0).poly, ref)
+    assert np.array_equal(g8.GenLookUpTableFull(lambda x: int(g8.Encoder.Encode(f(x)))).poly, ref)
+    # lut_test.go:163-189 ModSwitch stays in range at the key points; exact values at the quarters
+    g2 = lut.Generator(pkg.params.Security128Bit, 2)
+    pts = {0: 0, 1 << 30: 256, 1 << 31: 512, 3 << 30: 768, 0xFFFFFFFF: 0}
+    for x, want in pts.items():
+        assert g2.ModSwitch(x) == want

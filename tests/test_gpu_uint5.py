@@ -237,3 +237,30 @@ def test_dispatch_boundaries_uint_shapes(oracle, pkg, name, B):
     dec = np.array([oracle.decrypt_message(k.p, modulus, k.s0, np.ascontiguousarray(o)) for o in out])
     assert np.array_equal(dec, (3 * msgs + 1) % modulus), (name, B)
     ck.close()
+
+
+def test_bootstrap_func_like_the_reference_tests(oracle, pkg, keys80, ck80, keys_u5_small, ck_u5_small):
+    # evaluator/programmable_bootstrap_test.go:13-188 (identity / NOT / constant at modulus 2, 80-bit set) and
+    # params/uint_params_test.go:17-147 through the product's own lut.Generator and Evaluator.BootstrapFunc
+    k = keys80
+    ev = pkg.evaluator.Evaluator(ck80)
+    for f in (lambda x: x, lambda x: 1 - x, lambda x: 1):
+        for m in (0, 1):
+            ct = oracle.encrypt_message(k.p, k.rng, m, 2, k.s0)
+            out = ev.BootstrapFunc(ct, f, 2)
+            assert oracle.decrypt_message(k.p, 2, k.s0, np.ascontiguousarray(out)) == f(m)
+            # bit-identical to the oracle bootstrapping the oracle-generated table (N = 1024, L = 3: exact regime)
+            assert np.array_equal(out, oracle.bootstrap(k.p, k.bsk, k.ksk, ct, oracle.lut_generate(k.p, [f(0), f(1)])))
+    k5 = keys_u5_small
+    ev5 = pkg.evaluator.Evaluator(ck_u5_small)
+    sq = lambda x: (x * x + 3) % 32
+    table = pkg.lut.Generator(gpu_params(pkg, k5.p), 32).GenLookUpTable(sq)
+    msgs = [0, 1, 5, 16, 31]
+    cts = np.stack([oracle.encrypt_message(k5.p, k5.rng, m, 32, k5.s0) for m in msgs])
+    out = ev5.BatchBootstrapLUT(cts, table)
+    assert [oracle.decrypt_message(k5.p, 32, k5.s0, np.ascontiguousarray(o)) for o in out] == [sq(m) for m in msgs]
+    one = np.empty(k5.p.n + 1, np.uint32)
+    ev5.BootstrapFuncAssign(cts[2], sq, 32, one)
+    assert oracle.decrypt_message(k5.p, 32, k5.s0, one) == sq(5)
+    enc = pkg.lut.Encoder(32)
+    assert enc.Decode(oracle.phase(k5.p, k5.s0, one)) == sq(5)          # lut.Encoder.Decode on the decrypted phase
