@@ -44,7 +44,6 @@ __device__ __forceinline__ void load_lane_twiddles_512(LaneTwiddles512 &tw, cons
     tw.l2.w1 = table[kTw512Level2 + 1 * 32 + hl];
     tw.l2.w2 = table[kTw512Level2 + 2 * 32 + hl];
     tw.l2.w4 = table[kTw512Level2 + 4 * 32 + hl];
-    tw.l2.lds35_67 = nullptr;
 #pragma unroll
     for (int q = 0; q < 2; q++)
 #pragma unroll

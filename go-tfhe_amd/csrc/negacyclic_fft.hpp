@@ -68,14 +68,10 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 
 // A wave's DS operations are executed in issue order, so a wave-private LDS exchange only
 // needs the compiler kept from reordering/merging the accesses.
-#ifndef TFHE_NO_XCHG_PRIO
-// waves issuing an LDS exchange run at raised priority so the exchange gets into the (CU-shared)
-// LDS pipe early and its latency overlaps the other waves' fp64 work (-4 % blind-rotate time when applied to the batched forward exchanges; the same on the
-// inverse / partner exchanges measured +3 %, so only the forward path uses it)
+// Waves issuing an LDS exchange run at raised priority so the exchange gets into the (CU-shared) LDS pipe
+// early and its latency overlaps the other waves' fp64 work: -4 % blind-rotate time on the batched forward
+// exchanges; the same on the inverse / partner exchanges measured +3 %, so only the forward path uses it.
 #define TFHE_PRIO(n) __builtin_amdgcn_s_setprio(n)
-#else
-#define TFHE_PRIO(n)
-#endif
 
 __device__ __forceinline__ void wave_lds_order()
 {
@@ -105,7 +101,6 @@ constexpr int kTwCount1024 = 16 + 1024;
 // is what lets the key prefetch stay in registers.
 struct TwPow {
     cd w1, w2, w4;
-    const cd *lds35_67;   // optional: this lane's w^3, w^5, w^6, w^7 in an LDS table (stride 64), or nullptr
 };
 struct LaneTwiddles {
     TwPow l2, l3;
@@ -119,42 +114,16 @@ __device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &tw, const cd *_
     tw.l3.w1 = table[kTwLevel3 + 1 * 64 + lane];
     tw.l3.w2 = table[kTwLevel3 + 2 * 64 + lane];
     tw.l3.w4 = table[kTwLevel3 + 4 * 64 + lane];
-    tw.l2.lds35_67 = tw.l3.lds35_67 = nullptr;
-}
-
-// Workgroup-shared LDS copy of the derived powers (w^3, w^5, w^6, w^7 of levels 2 and 3): 8 KiB that
-// replace 32 fp64 multiplies per transform with 8 ds_read_b128 (the twiddles are the same for
-// every wave).  tab: [2][4][64] cd in LDS; call from all threads of the block, then barrier.
-__device__ __forceinline__ void fill_twiddle_lds(cd *tab, const cd *__restrict__ table, int tid, int nthreads)
-{
-    for (int idx = tid; idx < 2 * 4 * 64; idx += nthreads) {
-        const int lane = idx & 63, q = (idx >> 6) & 3, lvl = idx >> 8;
-        const int pw = q == 0 ? 3 : q == 1 ? 5 : q == 2 ? 6 : 7;
-        tab[idx] = table[(lvl ? kTwLevel3 : kTwLevel2) + pw * 64 + lane];
-    }
-}
-__device__ __forceinline__ void use_twiddle_lds(LaneTwiddles &tw, const cd *tab, int lane)
-{
-    tw.l2.lds35_67 = tab + lane;
-    tw.l3.lds35_67 = tab + 4 * 64 + lane;
 }
 
 // x[c] *= w^c (CONJ: conj(w)^c), c = 1..7, from w, w^2, w^4.  The empty asm makes w1 opaque so
 // the four derived powers are recomputed here instead of being hoisted out of the CMUX loop
-// (which would pin 16 more VGPRs per level).
+// (which would pin 16 more VGPRs per level and spills; an LDS table of them measured +3 %).
 template <bool CONJ> __device__ __forceinline__ void twist_pow(cd (&x)[8], const TwPow &t)
 {
     cd w1 = t.w1;
-    cd w3, w5, w6, w7;
-    if (t.lds35_67) {
-        w3 = t.lds35_67[0]; w5 = t.lds35_67[64]; w6 = t.lds35_67[128]; w7 = t.lds35_67[192];
-    } else {
-#ifndef TFHE_TW_HOIST
-        asm volatile("" : "+v"(w1.re), "+v"(w1.im));
-#endif
-        w3 = cmul(w1, t.w2); w5 = cmul(w1, t.w4); w6 = cmul(t.w2, t.w4);
-        w7 = cmul(w3, t.w4);
-    }
+    asm volatile("" : "+v"(w1.re), "+v"(w1.im));
+    const cd w3 = cmul(w1, t.w2), w5 = cmul(w1, t.w4), w6 = cmul(t.w2, t.w4), w7 = cmul(w3, t.w4);
     if (CONJ) {
         x[1] = cmulc(x[1], w1); x[2] = cmulc(x[2], t.w2); x[3] = cmulc(x[3], w3); x[4] = cmulc(x[4], t.w4);
         x[5] = cmulc(x[5], w5); x[6] = cmulc(x[6], w6); x[7] = cmulc(x[7], w7);
