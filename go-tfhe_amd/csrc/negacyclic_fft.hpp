@@ -133,6 +133,26 @@ template <bool CONJ> __device__ __forceinline__ void twist_pow(cd (&x)[8], const
     }
 }
 
+// The same twist with the four derived powers built ONCE by the caller (expand_pow) and shared by the
+// transforms of a batch.
+struct TwAll {
+    cd w3, w5, w6, w7;
+};
+__device__ __forceinline__ TwAll expand_pow(const TwPow &t)
+{
+    cd w1 = t.w1;
+    asm volatile("" : "+v"(w1.re), "+v"(w1.im));           // keep the rebuild inside the CMUX loop (see twist_pow)
+    TwAll a;
+    a.w3 = cmul(w1, t.w2); a.w5 = cmul(w1, t.w4); a.w6 = cmul(t.w2, t.w4);
+    a.w7 = cmul(a.w3, t.w4);
+    return a;
+}
+__device__ __forceinline__ void twist_all(cd (&x)[8], const TwPow &t, const TwAll &a)
+{
+    x[1] = cmul(x[1], t.w1); x[2] = cmul(x[2], t.w2); x[3] = cmul(x[3], a.w3); x[4] = cmul(x[4], t.w4);
+    x[5] = cmul(x[5], a.w5); x[6] = cmul(x[6], a.w6); x[7] = cmul(x[7], a.w7);
+}
+
 // Index u of the root zeta^(1+4u) held by (reg, lane) after the forward transform.
 __host__ __device__ __forceinline__ int spectrum_u_1024(int reg, int lane) { return (lane >> 3) + 8 * (lane & 7) + 64 * reg; }
 
@@ -199,9 +219,10 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
         wave_lds_order();
         TFHE_PRIO(0);
     }
+    const TwAll a2 = expand_pow(tw.l2);        // once per batch, not per transform: -56 VALU per CMUX step at L = 3
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-        twist_pow<false>(x[t], tw.l2);
+        twist_all(x[t], tw.l2, a2);
         dft8<1>(x[t]);
         TFHE_PRIO(3);
 #pragma unroll
@@ -212,9 +233,10 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
         wave_lds_order();
         TFHE_PRIO(0);
     }
+    const TwAll a3 = expand_pow(tw.l3);
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-        twist_pow<false>(x[t], tw.l3);
+        twist_all(x[t], tw.l3, a3);
         dft8<1>(x[t]);
     }
 }
