@@ -152,6 +152,16 @@ __device__ __forceinline__ void twist_all(cd (&x)[8], const TwPow &t, const TwAl
     x[1] = cmul(x[1], t.w1); x[2] = cmul(x[2], t.w2); x[3] = cmul(x[3], a.w3); x[4] = cmul(x[4], t.w4);
     x[5] = cmul(x[5], a.w5); x[6] = cmul(x[6], a.w6); x[7] = cmul(x[7], a.w7);
 }
+__device__ __forceinline__ void twist_all_conj(cd (&x)[8], const TwPow &t, const TwAll &a)
+{
+    x[1] = cmulc(x[1], t.w1); x[2] = cmulc(x[2], t.w2); x[3] = cmulc(x[3], a.w3); x[4] = cmulc(x[4], t.w4);
+    x[5] = cmulc(x[5], a.w5); x[6] = cmulc(x[6], a.w6); x[7] = cmulc(x[7], a.w7);
+}
+// Both levels' derived powers, for kernels with the registers to keep them across a whole CMUX step and share
+// them between the step's forward and inverse transforms (the N = 2048 blind rotate: one of each per wave).
+struct TwStep {
+    TwAll l2, l3;
+};
 
 // Index u of the root zeta^(1+4u) held by (reg, lane) after the forward transform.
 __host__ __device__ __forceinline__ int spectrum_u_1024(int reg, int lane) { return (lane >> 3) + 8 * (lane & 7) + 64 * reg; }
@@ -193,6 +203,56 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     wave_lds_order();
     twist_pow<false>(x, tw.l3);
     dft8<1>(x);
+}
+
+// The same transforms with the derived powers supplied by the caller (TwStep), no rebuild inside.
+__device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__restrict__ table,
+                                               const LaneTwiddles &tw, const TwStep &ts, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+    for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
+    dft8<1>(x);
+#pragma unroll
+    for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];
+    wave_lds_order();
+#pragma unroll
+    for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
+    wave_lds_order();
+    twist_all(x, tw.l2, ts.l2);
+    dft8<1>(x);
+#pragma unroll
+    for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];
+    wave_lds_order();
+#pragma unroll
+    for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
+    wave_lds_order();
+    twist_all(x, tw.l3, ts.l3);
+    dft8<1>(x);
+}
+__device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__restrict__ table,
+                                               const LaneTwiddles &tw, const TwStep &ts, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    dft8<-1>(x);
+    twist_all_conj(x, tw.l3, ts.l3);
+#pragma unroll
+    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    wave_lds_order();
+#pragma unroll
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    wave_lds_order();
+    dft8<-1>(x);
+    twist_all_conj(x, tw.l2, ts.l2);
+#pragma unroll
+    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    wave_lds_order();
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    wave_lds_order();
+    dft8<-1>(x);
+#pragma unroll
+    for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
 }
 
 // NB independent forward transforms advanced level by level through ONE scratch buffer: the
