@@ -8,7 +8,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(LIB_DIR, "libtfhe_hip.so")  # env override: kernel experiments
 # (source, extra flags): the fp64 kernels get the max-ILP machine scheduler, the rest the default one
 SOURCES = [("tfhe_hip.hip", []), ("blind_rotate.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
-HEADERS = ["kernels.hpp", "kernels_n2048.hpp", "negacyclic_fft.hpp", "launch_blind_rotate.hpp", os.path.join("..", "..", "include", "tfhe_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "tfhe_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

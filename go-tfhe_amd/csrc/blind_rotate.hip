@@ -4,10 +4,11 @@
 
 #include "kernels_n2048.hpp"
 #include "kernels_n512.hpp"
+#include "kernels_quad.hpp"
 
 namespace tfhe {
 
-void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cus, hipStream_t st)
+void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cus, int quad_limit, hipStream_t st)
 {
     // One launch covers at most the number of co-resident workgroups (28.8 KB LDS / 256 VGPRs -> 4 per CU
     // for N=1024; 55 KB LDS -> 2 per CU for N=2048).  All workgroups of such a launch walk the CMUX index in
@@ -15,6 +16,8 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
     // workgroups start as earlier ones finish) and becomes Infinity-Cache-bandwidth bound: 7.7 us per
     // bootstrap instead of 6.6; a persistent in-kernel item loop was tried and cost 9 % at B = 1024.
     // N=512: one wave and 16 KB LDS per bootstrap, 2 waves per SIMD -> 8 per CU.
+    // N = 1024, launches of up to quad_max items: four waves per bootstrap (kernels_quad.hpp)
+    const int quad_max = a0.bskq ? quad_limit : 0;
     const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 4 : 2) * num_cus;
     const size_t n1 = (size_t)a0.n + 1;
     const size_t trl = shape_is_512(shape) ? 2 * 512 : shape_is_1024(shape) ? 2 * 1024 : 2 * 2048;
@@ -28,6 +31,23 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         a.out = a0.out + base * trl;
         a.batch = cnt;
         const dim3 g(cnt);
+        if (shape_is_1024(shape) && cnt <= quad_max) {
+            // one workgroup per CU: one wave per SIMD, all key levels prefetched; two per CU: two waves per SIMD
+            if (cnt <= num_cus) {
+                switch (shape) {
+                case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 1>), g, dim3(256), 0, st, a); break;
+                case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate_quad<2, 10, 1, 1>), g, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_blind_rotate_quad<1, 23, 1, 1>), g, dim3(256), 0, st, a); break;
+                }
+            } else {
+                switch (shape) {
+                case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 2>), g, dim3(256), 0, st, a); break;
+                case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate_quad<2, 10, 1, 2>), g, dim3(256), 0, st, a); break;
+                default: hipLaunchKernelGGL((k_blind_rotate_quad<1, 23, 1, 2>), g, dim3(256), 0, st, a); break;
+                }
+            }
+            continue;
+        }
         // Several items per workgroup (they share only the barriers), measured A/B on one box:
         //   769..1024 items: FOUR per 8-wave workgroup = every resident wave of a CU in one workgroup, in step on
         //                    the key stream: 6.84 (one item) -> 6.66 (two) -> 6.38 ms (four) at 1024;

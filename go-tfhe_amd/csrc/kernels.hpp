@@ -78,6 +78,8 @@ struct BlindRotateArgs {
     int n, nsteps, Nbit;
     uint32_t offset;        // decomposition offset (cloudkey.go:60-71)
     int batch;              // items in this launch (only read by kernels that put several items in a workgroup)
+    const cd *bskq;         // the same key in the four-wave layout (kernels_quad.hpp), N = 1024 shapes only
+    const cd *twq;          // twiddle table of the four-wave kernel
 };
 
 constexpr int kMaxLweDim = 1280;      // Uint7/8 use n = 1160 (params.go:444-510)

@@ -1,0 +1,399 @@
+// kernels_quad.hpp -- small-batch blind rotate for the N = 1024 rings: FOUR wavefronts per bootstrap.
+//
+// k_blind_rotate (kernels.hpp) gives a bootstrap two waves; a launch of up to one workgroup per CU then
+// leaves two of the four SIMDs of every CU idle and each wave issues ~1,550 VALU instructions per CMUX
+// step at the ~8 cycles a lone wave needs per fp64 instruction: 5.0 us per step, 3.5 ms per blind rotate
+// whatever the batch (1..256).  Here wave (p, h) owns half h of the root tree of accumulator polynomial p:
+//
+//   X^512 - i = (X^256 - rho)(X^256 + rho), rho = exp(i pi/4):  y_h[j] = z_j + (-1)^h rho z_{j+256}, j < 256,
+//
+// and the two halves are independent 256-point transforms, run with FOUR points per lane in radix-4 levels
+// (polynomial remaindering mod X^64 - sigma, X^16 - tau, X^4 - upsilon, X - w: pre-twist by a unit root, then a
+// 4-point DFT in registers) and three lane<->register exchanges through a wave-private, unpadded,
+// conflict-free 4 KiB LDS scratch:
+//
+//   point j = 64a+16b+4c+d   level 1 (a -> m)  xchg   level 2 (b -> m')  xchg   level 3 (c -> m'')  xchg   level 4 (d -> m''')
+//   reg a, lane 16b+4c+d     -->  reg b, lane 16m+4c+d  -->  reg c, lane 16m+4m'+d  -->  reg d, lane 16m+4m'+m''
+//
+// leaving Z(zeta^(1+4u)), u = h + 2m + 8m' + 32m'' + 128m''', in (reg m''', lane 16m+4m'+m''); the
+// bootstrapping key is kept in that order as well (bskq_index).  Per CMUX step a wave runs L forward and one
+// inverse 256-point transform -- about 40 % of the instructions of a k_blind_rotate wave -- and meets the
+// others at TWO barriers: the partner-polynomial sum with wave (1-p, h) and the half swap with wave (p, 1-h)
+// that undoes the radix-2 level.  Every wave keeps a PRIVATE copy of its polynomial's accumulator (both
+// siblings compute the full update from the two half results; the additions are symmetric, so the copies stay
+// bit-identical), which removes the third barrier an accumulator shared by the siblings would need.
+// (evaluator.go:50-135; fourier_transform.go:178-347; decomposer.go:55-66)
+#pragma once
+
+#include "kernels.hpp"
+
+namespace tfhe {
+
+// Twiddle table, one block of kTwQuadHalf entries per half h (host: make_twiddles_quad):
+//   [0..3]   level-1 pre-twists  zeta^(64 a (1+4h))                    (wave-uniform)
+//   [4..7]   their conjugates / 512 (inverse level 1: 1/256 of the transform, 1/2 of the radix-2 level)
+//   [8 + ((lvl*3 + a-1)*64 + lane)], lvl = 0,1,2, a = 1,2,3:
+//            level-2 zeta^(16 a (1+4(h+2m))), level-3 zeta^(4 a (1+4(h+2m+8m'))), level-4 zeta^(a (1+4(h+2m+8m'+32m'')))
+//            with m = lane>>4, m' = (lane>>2)&3, m'' = lane&3.
+constexpr int kTwQuadHalf = 8 + 9 * 64;
+
+struct QuadTwiddles {
+    cd w[3][3];      // [level 2..4][a-1]
+};
+
+__device__ __forceinline__ void load_quad_twiddles(QuadTwiddles &tw, const cd *__restrict__ table /* half h */, int lane)
+{
+#pragma unroll
+    for (int lvl = 0; lvl < 3; lvl++)
+#pragma unroll
+        for (int a = 0; a < 3; a++) tw.w[lvl][a] = table[8 + (lvl * 3 + a) * 64 + lane];
+}
+
+// Spectrum index held by (half h, reg, lane) and the matching slot of the two-wave layout (kernels.hpp).
+__host__ __device__ __forceinline__ int spectrum_u_quad(int h, int reg, int lane)
+{
+    return h + 2 * (lane >> 4) + 8 * ((lane >> 2) & 3) + 32 * (lane & 3) + 128 * reg;
+}
+
+// cd bskq[n][2 (p)][2 (h)][L][2 (part)][4 (reg)][64 (lane)]: the 24 KiB a wave reads per step are contiguous.
+__host__ __device__ __forceinline__ size_t bskq_index(int L, int i, int p, int h, int l, int part, int reg, int lane)
+{
+    return (((((size_t)(i * 2 + p) * 2 + h) * L + l) * 2 + part) * 4 + reg) * 64 + lane;
+}
+
+// Two-wave layout -> quad layout (same values, permuted); one thread per complex.
+static __global__ void k_bsk_quad_from_wave(const cd *__restrict__ src, cd *__restrict__ dst, int n, int L)
+{
+    const size_t total = (size_t)n * 2 * L * 2 * 512;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, reg = (idx >> 6) & 3, part = (idx >> 8) & 1;
+    size_t rest = idx >> 9;
+    const int l = rest % L; rest /= L;
+    const int h = rest & 1, p = (rest >> 1) & 1;
+    const int i = (int)(rest >> 2);
+    const int u = spectrum_u_quad(h, reg, lane);
+    // kernels.hpp: u = m + 8m' + 64m'' at (reg m'', lane 8m+m')
+    dst[idx] = src[bsk_index(L, i, p, l, part, u >> 6, 8 * (u & 7) + ((u >> 3) & 7))];
+}
+
+// y_k = sum_n x_n i^(S n k), in place: 16 additions.
+template <int S> __device__ __forceinline__ void dft4(cd (&x)[4])
+{
+    const cd t0 = x[0] + x[2], t1 = x[0] - x[2], t2 = x[1] + x[3], t3 = mul_i<S>(x[1] - x[3]);
+    x[0] = t0 + t2; x[2] = t0 - t2; x[1] = t1 + t3; x[3] = t1 - t3;
+}
+
+// LDS slots (16 B each, 256 per wave) of the three exchanges; (hi, mid, lo) = the lane's three base-4 digits.
+//   exchange 1: element (reg m; lane b,c,d)      at 64m + 16b + 4c + d
+//   exchange 2: element (reg m'; lane m,c,d)     at 64m + 16m' + 4((c+m')&3) + d
+//   exchange 3: element (reg m''; lane m,m',d)   at 64m + 16m' + 4((m''+d)&3) + ((m'+d)&3)
+// Each ds_write_b128 (8 contiguous lanes per pass) and each ds_read_b128 (the four 16-lane service groups of
+// MI355X_MICROARCH.md, LDS) touches every slot residue mod 16 at most once, in both directions.
+struct QuadLane {
+    int lane, hi, mid, lo;
+};
+__device__ __forceinline__ QuadLane quad_lane(int lane) { return {lane, lane >> 4, (lane >> 2) & 3, lane & 3}; }
+
+// NB independent forward transforms advanced level by level through one scratch (in-order DS argument of
+// negacyclic_fft.hpp: fft512_forward_batch).  x[t][a] = y[64a + lane] in, spectrum order out.
+// Timing ablations (tools/build_variant.sh -DQUAD_ABL_*): results are garbage when any is set.
+#ifdef QUAD_ABL_NOXCHG_F
+#define QUAD_XF(stmt)
+#else
+#define QUAD_XF(stmt) _Pragma("unroll") stmt
+#endif
+#ifdef QUAD_ABL_NOXCHG_I
+#define QUAD_XI(stmt)
+#else
+#define QUAD_XI(stmt) _Pragma("unroll") stmt
+#endif
+#ifdef QUAD_ABL_NOBAR
+#define QUAD_SYNC()
+#else
+#define QUAD_SYNC() __syncthreads()
+#endif
+#ifdef QUAD_ABL_HOTKEY            /* every step reads step 0's key: L1/L2-hot */
+#define QUAD_KEYSTEP(i) 0
+#else
+#define QUAD_KEYSTEP(i) (i)
+#endif
+#ifdef QUAD_PRIO
+#define QUAD_PRIO_HI() TFHE_PRIO(3)
+#define QUAD_PRIO_LO() TFHE_PRIO(0)
+#else
+#define QUAD_PRIO_HI()
+#define QUAD_PRIO_LO()
+#endif
+#ifdef QUAD_STAGGER
+#define QUAD_PIN() __builtin_amdgcn_sched_barrier(0)
+#else
+#define QUAD_PIN()
+#endif
+
+template <int NB>
+__device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw,
+                                                     const QuadLane q)
+{
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+#pragma unroll
+        for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], T[a]);
+        dft4<1>(x[t]);
+        QUAD_PRIO_HI();
+        QUAD_XF(for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];)
+        wave_lds_order();
+        QUAD_XF(for (int b = 0; b < 4; b++) x[t][b] = sc[64 * q.hi + 16 * b + (q.lane & 15)];)
+        wave_lds_order();
+        QUAD_PRIO_LO();
+        QUAD_PIN();
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+#pragma unroll
+        for (int b = 1; b < 4; b++) x[t][b] = cmul(x[t][b], tw.w[0][b - 1]);
+        dft4<1>(x[t]);
+        QUAD_PRIO_HI();
+        QUAD_XF(for (int mp = 0; mp < 4; mp++) sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo] = x[t][mp];)
+        wave_lds_order();
+        QUAD_XF(for (int c = 0; c < 4; c++) x[t][c] = sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo];)
+        wave_lds_order();
+        QUAD_PRIO_LO();
+        QUAD_PIN();
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+#pragma unroll
+        for (int c = 1; c < 4; c++) x[t][c] = cmul(x[t][c], tw.w[1][c - 1]);
+        dft4<1>(x[t]);
+        QUAD_PRIO_HI();
+        QUAD_XF(for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.mid + 4 * ((mpp + q.lo) & 3) + ((q.mid + q.lo) & 3)] = x[t][mpp];)
+        wave_lds_order();
+        QUAD_XF(for (int d = 0; d < 4; d++) x[t][d] = sc[64 * q.hi + 16 * q.mid + 4 * ((q.lo + d) & 3) + ((q.mid + d) & 3)];)
+        wave_lds_order();
+        QUAD_PRIO_LO();
+        QUAD_PIN();
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+#pragma unroll
+        for (int d = 1; d < 4; d++) x[t][d] = cmul(x[t][d], tw.w[2][d - 1]);
+        dft4<1>(x[t]);
+    }
+}
+
+// Inverse (includes the 1/512 of the whole 512-point transform): spectrum order in, x[a] = y_h[64a + lane] / 2 out.
+__device__ __forceinline__ void fft256_inverse(cd (&x)[4], cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q)
+{
+    dft4<-1>(x);
+#pragma unroll
+    for (int d = 1; d < 4; d++) x[d] = cmulc(x[d], tw.w[2][d - 1]);
+    QUAD_XI(for (int d = 0; d < 4; d++) sc[64 * q.hi + 16 * q.mid + 4 * ((q.lo + d) & 3) + ((q.mid + d) & 3)] = x[d];)
+    wave_lds_order();
+    QUAD_XI(for (int mpp = 0; mpp < 4; mpp++) x[mpp] = sc[64 * q.hi + 16 * q.mid + 4 * ((mpp + q.lo) & 3) + ((q.mid + q.lo) & 3)];)
+    wave_lds_order();
+    dft4<-1>(x);
+#pragma unroll
+    for (int c = 1; c < 4; c++) x[c] = cmulc(x[c], tw.w[1][c - 1]);
+    QUAD_XI(for (int c = 0; c < 4; c++) sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo] = x[c];)
+    wave_lds_order();
+    QUAD_XI(for (int mp = 0; mp < 4; mp++) x[mp] = sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo];)
+    wave_lds_order();
+    dft4<-1>(x);
+#pragma unroll
+    for (int b = 1; b < 4; b++) x[b] = cmulc(x[b], tw.w[0][b - 1]);
+    QUAD_XI(for (int b = 0; b < 4; b++) sc[64 * q.hi + 16 * b + (q.lane & 15)] = x[b];)
+    wave_lds_order();
+    QUAD_XI(for (int m = 0; m < 4; m++) x[m] = sc[64 * m + q.lane];)
+    wave_lds_order();
+    dft4<-1>(x);
+#pragma unroll
+    for (int a = 0; a < 4; a++) x[a] = cmul(x[a], T[4 + a]);
+}
+
+// Key slices of one gadget level for one wave: {keep, send} x 4 registers (32 VGPRs).
+struct QuadKeys {
+    cd keep[4], send[4];
+};
+__device__ __forceinline__ void load_quad_keys(QuadKeys &K, const cd *__restrict__ key_iphl /* &bskq[i][p][h][l] */, int p, int lane)
+{
+    const cd *kA = key_iphl + lane, *kB = kA + 256;
+    const cd *kKeep = p ? kB : kA, *kSend = p ? kA : kB;       // wave p keeps output p
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        K.keep[k] = kKeep[k * 64];
+        K.send[k] = kSend[k * 64];
+    }
+}
+
+// One workgroup = 4*ITEMS waves = ITEMS bootstraps; wave w: item w>>2, polynomial p = (w>>1)&1, half h = w&1.
+// WPS = waves per SIMD the launch shape needs (register budget 512 / WPS).  KD = key levels fetched at the top
+// of a step: L (all of them, 32 L VGPRs, for one wave per SIMD where nothing else hides the L2 latency) or 1
+// (level 0 at the top, level l+1 under the products of level l, as k_blind_rotate does).
+#ifndef QUAD_KD1
+#define QUAD_KD_DEFAULT (WPS == 1 ? L : 1)
+#else
+#define QUAD_KD_DEFAULT 1
+#endif
+template <int L, int BGBIT, int ITEMS, int WPS, int KD = QUAD_KD_DEFAULT>
+__global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRotateArgs A)
+{
+    constexpr int N = 1024, W = 4 * ITEMS;
+    constexpr double r = 0.70710678118654752440;
+    __shared__ cd scAll[W][256];            // FFT exchanges
+    __shared__ cd sendAll[W][256];          // partner-polynomial hand-over
+    __shared__ cd swapAll[W][256];          // half swap
+    __shared__ uint32_t accAll[W][N];       // private accumulator copies
+    __shared__ uint16_t abarAll[ITEMS][kMaxLweDim];
+    __shared__ int btAll[ITEMS];
+
+    const int lane = threadIdx.x & 63, tid = threadIdx.x & 255;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int grp = ITEMS > 1 ? w >> 2 : 0, p = (w >> 1) & 1, h = w & 1;
+    uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
+    int &btL = btAll[grp];
+    uint32_t *acc = accAll[w];
+    cd *sc = scAll[w];
+    int item = blockIdx.x * ITEMS + grp;
+    const bool live = ITEMS == 1 || item < A.batch;
+    if (!live) item = A.batch - 1;              // ragged batch: the idle group recomputes the last item, stores nothing
+    const int n = A.n;
+
+    // ---- gate linear prep + mod-switch (gates_helper.go:10-63, evaluator.go:116,122)
+    {
+        const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
+        const GateCoef g = gate_coef(A.in1 ? op : -1);
+        const uint32_t *x0 = A.in0 + (size_t)item * (n + 1);
+        const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
+        const int sh = 32 - A.Nbit - 1;
+        const uint32_t rnd = 1u << (sh - 1);
+        for (int x = tid; x <= n; x += 256) {
+            uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
+            if (x == n) {
+                v += g.cst;
+                btL = 2 * N - (int)(((unsigned long long)v + rnd) >> sh);     // int add, no 32-bit wrap (evaluator.go:116)
+            } else {
+                abarL[x] = (uint16_t)((uint32_t)(v + rnd) >> sh);             // wraps (evaluator.go:122)
+            }
+        }
+    }
+    const cd *T = A.twq + (size_t)h * kTwQuadHalf;
+    QuadTwiddles tw;
+    load_quad_twiddles(tw, T, lane);
+    const QuadLane q = quad_lane(lane);
+    __syncthreads();
+
+    // ---- acc = X^bt * testvec, this wave's own copy of polynomial p (evaluator.go:117-118, buffer_methods.go:133-164)
+    {
+        const int bt = btL & (2 * N - 1);
+        const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = 64 * k + lane;
+            const int s = (j - bt) & (2 * N - 1);
+            uint32_t v = tv[s & (N - 1)];
+            v ^= 0u - (uint32_t)((s >> 10) & 1);      // "negation" is the bitwise complement
+            acc[j] = v;
+        }
+    }
+    wave_lds_order();
+
+    constexpr size_t kStep = (size_t)2 * L * 2 * 512;            // cd per CMUX step
+    const cd *key = A.bskq + ((size_t)p * 2 + h) * (L * 2 * 256);
+    const int partner = w ^ 2, sibling = w ^ 1;
+    const double sr = h ? -r : r;                                // (-1)^h / sqrt2
+    constexpr uint32_t mask = (1u << BGBIT) - 1u;
+    constexpr int half = 1 << (BGBIT - 1);
+    constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;      // see external_product_core
+    const int nsteps = A.nsteps;
+    for (int i = 0; i < nsteps; i++) {
+        const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        // this step's key slices: issued first, they land under the decomposition and the forward transforms
+        QuadKeys K[KD];
+#pragma unroll
+        for (int l = 0; l < KD; l++) load_quad_keys(K[l], key + (size_t)QUAD_KEYSTEP(i) * kStep + (size_t)l * 512, p, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // d = X^at*acc - acc (evaluator.go:93-96,122-126), decomposed (decomposer.go:55-66) and folded to this
+        // half-tree: y_h[j] = dig(z_j) + (-1)^h rho dig(z_{j+256}), z_j = d_j + i d_{j+512}.  rho*(a+ib) =
+        // ((a-b) + i(a+b))/sqrt2 with a-b, a+b formed on the integer digits.
+        cd x[L][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            uint32_t dd[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 64 * a + lane + 256 * k;          // k = 0: re lo, 1: re hi (j+256), 2: im lo (j+512), 3: im hi
+                const int s = (j - at) & (2 * N - 1);
+                uint32_t v = acc[s & (N - 1)];
+                v ^= 0u - (uint32_t)((s >> 10) & 1);
+                dd[k] = v - acc[j] + A.offset;
+            }
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int shift = 32 - (l + 1) * BGBIT;
+                const int lo_re = (int)((dd[0] >> shift) & mask) - half, hi_re = (int)((dd[1] >> shift) & mask) - half;
+                const int lo_im = (int)((dd[2] >> shift) & mask) - half, hi_im = (int)((dd[3] >> shift) & mask) - half;
+                x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
+            }
+        }
+        fft256_forward_batch<L>(x, sc, T, tw, q);
+        cd keep[4], send[4];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+            const QuadKeys &Kl = K[KD == 1 ? 0 : l];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (l == 0) {
+                    keep[k] = cmul(x[0][k], Kl.keep[k]);
+                    send[k] = cmul(x[0][k], Kl.send[k]);
+                } else {
+                    cfma(keep[k], x[l][k], Kl.keep[k]);
+                    cfma(send[k], x[l][k], Kl.send[k]);
+                }
+            }
+            if (KD == 1 && l + 1 < L) {
+                // anchor the products before the registers are refilled (see external_product_core)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    asm volatile("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
+                __builtin_amdgcn_sched_barrier(0);
+                load_quad_keys(K[0], key + (size_t)QUAD_KEYSTEP(i) * kStep + (size_t)(l + 1) * 512, p, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) sendAll[w][k * 64 + lane] = send[k];
+        QUAD_SYNC();
+#pragma unroll
+        for (int k = 0; k < 4; k++) keep[k] = keep[k] + sendAll[partner][k * 64 + lane];
+        fft256_inverse(keep, sc, T, tw, q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) swapAll[w][k * 64 + lane] = keep[k];
+        QUAD_SYNC();
+        // undo the radix-2 level: z_j = y0 + y1, z_{j+256} = conj(rho)(y0 - y1) (the 1/2 is in the inverse's scale);
+        // own - other = (-1)^h (y0 - y1).  acc += round(.) on the private copy (evaluator.go:102-105).
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const cd o = swapAll[sibling][a * 64 + lane];
+            const cd s = keep[a] + o, dl = keep[a] - o;
+            const double e1r = (dl.re + dl.im) * sr, e1i = (dl.im - dl.re) * sr;
+            const int j = 64 * a + lane;
+            acc[j] += kSmall ? round_to_torus_small(s.re) : round_to_torus_wide(s.re);
+            acc[j + 512] += kSmall ? round_to_torus_small(s.im) : round_to_torus_wide(s.im);
+            acc[j + 256] += kSmall ? round_to_torus_small(e1r) : round_to_torus_wide(e1r);
+            acc[j + 768] += kSmall ? round_to_torus_small(e1i) : round_to_torus_wide(e1i);
+        }
+        wave_lds_order();
+    }
+
+    if (!live) return;
+    // wave (p, h) stores coefficient blocks [256h, 256h+256) and [512+256h, 512+256h+256) of polynomial p
+    uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int j = 64 * (k & 3) + lane + 256 * h + 512 * (k >> 2);
+        out[j] = acc[j];
+    }
+}
+
+} // namespace tfhe

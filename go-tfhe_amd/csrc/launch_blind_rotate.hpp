@@ -17,8 +17,9 @@ enum Shape { kShapeN1024_L3_B6 = 1,   // 80/110/128-bit sets
              kShapeN512_L1_B18 = 5 }; // Uint2
 inline bool shape_is_1024(int shape) { return shape != kShapeN2048_L1_B22 && shape != kShapeN512_L1_B18; }
 inline bool shape_is_512(int shape) { return shape == kShapeN512_L1_B18; }
-// B items in launches of at most the co-resident workgroup count (4 per CU for N=1024, 2 per CU for N=2048)
-void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, int num_cus, hipStream_t st);
+// B items in launches of at most the co-resident workgroup count (4 per CU for N=1024, 2 per CU for N=2048).
+// quad_limit: N = 1024 launches of up to this many items use the four-wave kernel (kernels_quad.hpp).
+void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, int num_cus, int quad_limit, hipStream_t st);
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
                              uint32_t offset, int B, hipStream_t st);
 } // namespace tfhe

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -18,6 +19,7 @@
 #include "kernels.hpp"
 #include "kernels_n2048.hpp"
 #include "kernels_n512.hpp"
+#include "kernels_quad.hpp"
 #include "launch_blind_rotate.hpp"
 #include "keygen.hpp"
 
@@ -79,6 +81,7 @@ struct tfhe_ctx {
     uint32_t offset = 0;        // cloudkey.go:60-71
     int n1p = 0;                // padded LWE row length of the packed KSK
     int num_cus = 256;          // hipDeviceProp_t.multiProcessorCount
+    int quad_limit = 0;         // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
     hipStream_t stream = nullptr;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool ev_valid[2] = {false, false};
@@ -87,6 +90,7 @@ struct tfhe_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev[2];
     std::vector<hipEvent_t> ev_pool;
     DevBuf bsk, ksk, tw, gate_tv;
+    DevBuf bskq, twq;           // four-wave layout of the key + its twiddles (N = 1024 shapes, kernels_quad.hpp)
     bool have_bsk = false, have_ksk = false;
     // staging (grow-only)
     DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_t0, s_t1, s_t2, s_t3;
@@ -149,6 +153,37 @@ std::vector<cd> make_twiddles(int N)
     return t;
 }
 
+// Twiddle table of the four-wave kernel (kernels_quad.hpp layout), N = 1024: root index
+// u = h + 2m + 8m' + 32m'' + 128m'''.
+std::vector<cd> make_twiddles_quad()
+{
+    const int N = 1024;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    auto zeta = [&](long e) {
+        e %= 2L * N; if (e < 0) e += 2L * N;
+        long double a = pi * (long double)e / (long double)N;
+        return cd{(double)cosl(a), (double)sinl(a)};
+    };
+    std::vector<cd> t((size_t)2 * kTwQuadHalf);
+    for (int h = 0; h < 2; h++) {
+        cd *T = t.data() + (size_t)h * kTwQuadHalf;
+        for (int a = 0; a < 4; a++) {
+            T[a] = zeta(64L * a * (1 + 4 * h));
+            const cd c = zeta(-64L * a * (1 + 4 * h));
+            T[4 + a] = cd{c.re / 512.0, c.im / 512.0};
+        }
+        for (int lane = 0; lane < 64; lane++) {
+            const int m = lane >> 4, mp = (lane >> 2) & 3, mpp = lane & 3;
+            for (int a = 1; a < 4; a++) {
+                T[8 + (0 * 3 + a - 1) * 64 + lane] = zeta(16L * a * (1 + 4 * (h + 2 * m)));
+                T[8 + (1 * 3 + a - 1) * 64 + lane] = zeta(4L * a * (1 + 4 * (h + 2 * m + 8 * mp)));
+                T[8 + (2 * 3 + a - 1) * 64 + lane] = zeta((long)a * (1 + 4 * (h + 2 * m + 8 * mp + 32 * mpp)));
+            }
+        }
+    }
+    return t;
+}
+
 // Event pair bracketing one launch of kernel `which` on stream st.
 int timing_begin(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t *stop)
 {
@@ -174,6 +209,19 @@ int check_ctx(tfhe_ctx *c)
     return TFHE_OK;
 }
 
+// After any key load / keygen on an N = 1024 shape: derive the four-wave layout from the two-wave one.
+int make_quad_key(tfhe_ctx *c, hipStream_t st)
+{
+    if (!shape_is_1024(c->shape)) return TFHE_OK;
+    const size_t elems = bsk_elems(c->P);
+    int rc;
+    if ((rc = c->bskq.reserve(elems * sizeof(cd)))) return rc;
+    hipLaunchKernelGGL(k_bsk_quad_from_wave, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, c->bsk.as<cd>(),
+                       c->bskq.as<cd>(), c->P.n, c->P.L);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
 int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in1, const uint8_t *d_ops,
                         int op_uniform, const uint32_t *d_tv, int tv_per_item, uint32_t *d_out, int B, int nsteps,
                         hipStream_t st)
@@ -183,6 +231,7 @@ int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in
     BlindRotateArgs a{};
     a.bsk = c->bsk.as<cd>();
     a.tw = c->tw.as<cd>();
+    a.bskq = c->bskq.as<cd>(); a.twq = c->twq.as<cd>();
     a.in0 = d_in0; a.in1 = d_in1; a.ops = d_ops; a.op_uniform = op_uniform;
     a.tv = d_tv ? d_tv : c->gate_tv.as<uint32_t>();
     a.tv_stride = (d_tv && tv_per_item) ? 2L * c->P.N : 0;
@@ -193,7 +242,7 @@ int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in
     hipEvent_t stop;
     int trc = timing_begin(c, 0, st, &stop);
     if (trc) return trc;
-    launch_blind_rotate(c->shape, a, B, c->num_cus, st);
+    launch_blind_rotate(c->shape, a, B, c->num_cus, c->quad_limit, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(stop, st));
     c->ev_valid[0] = !c->timing;
@@ -375,6 +424,11 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
+    {
+        // tuning override for A/B measurements (tools/): TFHE_QUAD_MAX=0 keeps every launch on the two-wave kernel
+        const char *e = getenv("TFHE_QUAD_MAX");
+        c->quad_limit = e ? atoi(e) : c->num_cus;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
@@ -382,6 +436,11 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     int rc;
     if ((rc = c->tw.reserve(tw.size() * sizeof(cd)))) return rc;
     HIP_TRY(hipMemcpy(c->tw.p, tw.data(), tw.size() * sizeof(cd), hipMemcpyHostToDevice));
+    if (shape_is_1024(shape)) {
+        std::vector<cd> twq = make_twiddles_quad();
+        if ((rc = c->twq.reserve(twq.size() * sizeof(cd)))) return rc;
+        HIP_TRY(hipMemcpy(c->twq.p, twq.data(), twq.size() * sizeof(cd), hipMemcpyHostToDevice));
+    }
     std::vector<uint32_t> tv(2 * (size_t)P->N, 0u);              // cloudkey.go:74-85
     for (int j = 0; j < P->N; j++) tv[P->N + j] = 0x20000000u;
     if ((rc = c->gate_tv.reserve(tv.size() * sizeof(uint32_t)))) return rc;
@@ -396,7 +455,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     if (!c) return TFHE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->bsk, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
+    for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
                       &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3})
         b->release();
     for (auto &pair : c->ev)
@@ -444,6 +503,7 @@ int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
         hipLaunchKernelGGL(k_bsk_from_fourier_2048, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, c->stream,
                            raw.as<double>(), c->bsk.as<cd>(), c->P.n);
     HIP_TRY(hipGetLastError());
+    if ((rc = make_quad_key(c, c->stream))) { raw.release(); return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     raw.release();
     c->have_bsk = true;
@@ -470,6 +530,7 @@ int tfhe_load_bsk_torus(tfhe_ctx *c, const uint32_t *bsk)
         hipLaunchKernelGGL(k_bsk_from_torus_2048, dim3((unsigned)polys), dim3(64), 0, c->stream, raw.as<uint32_t>(),
                            c->bsk.as<cd>(), c->tw.as<cd>());
     HIP_TRY(hipGetLastError());
+    if ((rc = make_quad_key(c, c->stream))) { raw.release(); return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     raw.release();
     c->have_bsk = true;
@@ -544,6 +605,7 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
     hipLaunchKernelGGL(k_keygen_ksk, dim3((unsigned)rows_p), dim3(64), 0, st, c->ksk.as<uint32_t>(), d_s0.as<uint32_t>(),
                        d_s1.as<uint32_t>(), P.n, c->n1p, P.t, P.basebit, rows_p, alpha_lv0, seed ^ 0x9E3779B97F4A7C15ull);
     HIP_TRY(hipGetLastError());
+    if ((rc = make_quad_key(c, st))) { d_s0.release(); d_s1.release(); d_spec.release(); return rc; }
     HIP_TRY(hipStreamSynchronize(st));
     d_s0.release(); d_s1.release(); d_spec.release();
     c->have_bsk = c->have_ksk = true;

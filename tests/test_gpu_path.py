@@ -289,8 +289,8 @@ def test_paired_workgroup_launch_bit_exact(oracle, keys_small, ck_small, pkg, B)
 
 @pytest.mark.parametrize("B", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 513, 767, 768, 769, 770, 1021, 1023, 1025, 2049])
 def test_dispatch_boundaries_gate_shape(oracle, keys_small, ck_small, pkg, B):
-    # Every batch-size threshold of the launchers, both sides: gather / tiled key switch (32), one workgroup
-    # per CU (256), two items per workgroup (257..512), one (513..768), four (769..1024, ragged last workgroup
+    # Every batch-size threshold of the launchers, both sides: gather / tiled key switch (32), the four-wave
+    # kernel up to one workgroup per CU (256), two items per workgroup (257..512), one (513..768), four (769..1024, ragged last workgroup
     # with 1..3 idle wave pairs), chunked launches beyond 1024.
     # Whole gates (prep + blind rotate + extract + key switch) are bit-exact against the oracle.
     k = keys_small
@@ -306,6 +306,42 @@ def test_dispatch_boundaries_gate_shape(oracle, keys_small, ck_small, pkg, B):
     uni = ck_small.ctx.gate_batch("NAND", a, b)
     sel = np.where(names == "NAND")[0]
     assert np.array_equal(uni[sel], out[sel])
+
+
+@pytest.mark.parametrize("which", ["small", "uint1", "uint3"])
+def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which, monkeypatch):
+    # kernels_quad.hpp (launches of <= one workgroup per CU) against kernels.hpp on the same key and inputs: the
+    # accumulators are bit-identical word for word at every prefix of the CMUX chain, for all three N = 1024
+    # gadget shapes (L=3/Bg=2^6: exact regime, whole chains; Uint1 L=2/Bg=2^10 and Uint3 L=1/Bg=2^23: tolerance
+    # regime, one product).
+    if which == "small":
+        p, bsk_t = keys_small.p, keys_small.bsk_torus
+    else:
+        p = oracle.params(which).small(16)
+        bsk_t = rand_u32(np.random.RandomState(5), (p.n, 2 * p.L, 2, p.N))
+    ksk = np.zeros((p.N * p.t * (1 << p.basebit), p.n + 1), np.uint32)
+    monkeypatch.setenv("TFHE_QUAD_MAX", "0")
+    ck2 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
+    monkeypatch.setenv("TFHE_QUAD_MAX", "1000000")
+    ck4 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
+    monkeypatch.delenv("TFHE_QUAD_MAX")
+    rs = np.random.RandomState(21)
+    for B in (1, 5, 300):            # 300 > one workgroup per CU: the two-per-CU instance of the four-wave kernel
+        cts = rand_u32(rs, (B, p.n + 1))
+        cts[0] = 0
+        tvs = rand_u32(rs, (B, 2, p.N))
+        for nsteps in ((0, 1, 3, -1) if which == "small" else (0, 1)):
+            a, b = ck2.ctx.blind_rotate_batch(cts, tvs, nsteps), ck4.ctx.blind_rotate_batch(cts, tvs, nsteps)
+            if which == "small":
+                assert np.array_equal(a, b), (B, nsteps)
+            else:
+                # values reach 2^52 / 2^64 here: not exact integers for any fp64 pipeline, and one
+                # differing low bit flips a digit of the next step, so only ONE product is comparable: the two
+                # transform orders agree to within twice the per-product bound of test_gpu_uint5.py
+                tol = 2 * (2**4 if which == "uint1" else 2**12)
+                diff = (a.astype(np.int64) - b.astype(np.int64) + 2**31) % 2**32 - 2**31
+                assert np.abs(diff).max() <= tol, (which, B, nsteps, np.abs(diff).max())
+    ck2.close(); ck4.close()
 
 
 def test_concurrent_host_threads(oracle, keys_small, ck_small, pkg):
