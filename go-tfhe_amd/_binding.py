@@ -57,6 +57,8 @@ def load_library():
         "tfhe_load_bsk_torus": [vp, u32p],
         "tfhe_load_ksk": [vp, u32p],
         "tfhe_keygen_cloud": [vp, u32p, u32p, C.c_double, C.c_double, C.c_uint64],
+        "tfhe_ctx_reserve": [vp, C.c_int, C.c_int],
+        "tfhe_keygen_cloud_seeded": [vp, u32p, u32p, C.c_double, C.c_double, C.POINTER(C.c_uint64)],
         "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
         "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
         "tfhe_blind_rotate_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int, C.c_int],
@@ -98,14 +100,23 @@ def _p32(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint32)) if a is not None else None
 
 
-def _devptr(t):
-    """Device pointer of a torch tensor (or a raw int / None)."""
+def _devptr(t, shape=None, device=None, itemsize=4, what="tensor"):
+    """Device pointer of a torch tensor (or a raw int / None).  With `shape`, the tensor is checked against it
+    (a mismatch would otherwise be an out-of-bounds device access, not an error): element size (int32/uint32 words,
+    or bytes for op codes), exact shape, contiguity, and that it lives on the context's GPU."""
     if t is None:
         return None
     if isinstance(t, int):
         return C.c_void_p(t)
     if not t.is_cuda or not t.is_contiguous():
-        raise ValueError("device variants need contiguous GPU tensors")
+        raise ValueError(f"{what}: device variants need contiguous GPU tensors")
+    if shape is not None:
+        if t.element_size() != itemsize or t.dtype.is_floating_point:
+            raise ValueError(f"{what}: expected {itemsize}-byte integer elements, got {t.dtype}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        if device is not None and t.device.index != device:
+            raise ValueError(f"{what}: lives on cuda:{t.device.index}, the context on cuda:{device}")
     return C.c_void_p(t.data_ptr())
 
 
@@ -144,7 +155,7 @@ class Context:
         self._h = C.c_void_p()
         self.params = params
         self._check(self._lib.tfhe_ctx_create(C.byref(params), int(device), C.byref(self._h)))
-        self.device = device
+        self.device = int(device)
 
     def _check(self, rc):
         if rc != 0:
@@ -179,12 +190,21 @@ class Context:
         ksk = _u32(ksk, (p.ksk_rows, p.n + 1))
         self._check(self._lib.tfhe_load_ksk(self._h, _p32(ksk)))
 
-    def keygen_cloud(self, s0, s1, alpha_lv0, alpha_lv1, seed):
-        """cloudkey.NewCloudKey on the GPU from the binary secret keys (no key upload)."""
+    def keygen_cloud(self, s0, s1, alpha_lv0, alpha_lv1, seed=None):
+        """cloudkey.NewCloudKey on the GPU from the binary secret keys (no key upload).
+        seed: None = 128 bits from the OS entropy source (the library calls getrandom); an int < 2**128 = a fixed
+        seed, FOR TESTS ONLY: the seed determines every mask and noise sample of the cloud key, so it is secret
+        key material (include/tfhe_hip.h)."""
         p = self.params
         s0, s1 = _u32(s0, (p.n,)), _u32(s1, (p.N,))
-        self._check(self._lib.tfhe_keygen_cloud(self._h, _p32(s0), _p32(s1), float(alpha_lv0), float(alpha_lv1),
-                                                C.c_uint64(int(seed))))
+        if seed is None:
+            sp = None
+        else:
+            seed = int(seed)
+            if not 0 <= seed < 1 << 128:
+                raise ValueError("seed must be a non-negative integer below 2**128")
+            sp = (C.c_uint64 * 2)(seed & (2**64 - 1), seed >> 64)
+        self._check(self._lib.tfhe_keygen_cloud_seeded(self._h, _p32(s0), _p32(s1), float(alpha_lv0), float(alpha_lv1), sp))
 
     # ---- host-pointer entry points
     def _tv(self, tv, B):
@@ -283,33 +303,47 @@ class Context:
         return C.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
 
     def gate_batch_dev(self, ops, a, b, c, out, stream=None):
-        B = a.shape[0]
+        B, n1, d = a.shape[0], self.params.n + 1, self.device
         if isinstance(ops, str):
             opp, uni = None, OPS[ops]
         else:
-            opp, uni = _devptr(ops), -1
-        self._check(self._lib.tfhe_gate_batch_dev(self._h, opp, uni, _devptr(a), _devptr(b), _devptr(c), _devptr(out),
-                                                  B, self._stream(stream)))
+            opp, uni = _devptr(ops, (B,), d, 1, "ops"), -1
+        self._check(self._lib.tfhe_gate_batch_dev(self._h, opp, uni, _devptr(a, (B, n1), d, what="a"),
+                                                  _devptr(b, (B, n1), d, what="b"), _devptr(c, (B, n1), d, what="c"),
+                                                  _devptr(out, (B, n1), d, what="out"), B, self._stream(stream)))
+
+    def _tv_dev(self, testvec, B):
+        if testvec is None:
+            return None, 0
+        N, per = self.params.N, 1 if testvec.dim() == 3 else 0
+        return _devptr(testvec, (B, 2, N) if per else (2, N), self.device, what="testvec"), per
 
     def bootstrap_batch_dev(self, cts, testvec, out, stream=None):
-        B = cts.shape[0]
-        per = 1 if (testvec is not None and testvec.dim() == 3) else 0
-        self._check(self._lib.tfhe_bootstrap_batch_dev(self._h, _devptr(cts), _devptr(testvec), per, _devptr(out), B,
-                                                       self._stream(stream)))
+        B, n1, d = cts.shape[0], self.params.n + 1, self.device
+        tvp, per = self._tv_dev(testvec, B)
+        self._check(self._lib.tfhe_bootstrap_batch_dev(self._h, _devptr(cts, (B, n1), d, what="cts"), tvp, per,
+                                                       _devptr(out, (B, n1), d, what="out"), B, self._stream(stream)))
 
     def blind_rotate_batch_dev(self, cts, testvec, out, nsteps=-1, stream=None):
-        B = cts.shape[0]
-        per = 1 if (testvec is not None and testvec.dim() == 3) else 0
-        self._check(self._lib.tfhe_blind_rotate_batch_dev(self._h, _devptr(cts), _devptr(testvec), per, _devptr(out),
+        B, n1, d = cts.shape[0], self.params.n + 1, self.device
+        tvp, per = self._tv_dev(testvec, B)
+        self._check(self._lib.tfhe_blind_rotate_batch_dev(self._h, _devptr(cts, (B, n1), d, what="cts"), tvp, per,
+                                                          _devptr(out, (B, 2, self.params.N), d, what="out"),
                                                           B, int(nsteps), self._stream(stream)))
 
     def extract_keyswitch_batch_dev(self, trlwe, out, stream=None):
-        B = trlwe.shape[0]
-        self._check(self._lib.tfhe_extract_keyswitch_batch_dev(self._h, _devptr(trlwe), _devptr(out), B,
+        B, d = trlwe.shape[0], self.device
+        self._check(self._lib.tfhe_extract_keyswitch_batch_dev(self._h, _devptr(trlwe, (B, 2, self.params.N), d, what="trlwe"),
+                                                               _devptr(out, (B, self.params.n + 1), d, what="out"), B,
                                                                self._stream(stream)))
 
     def sync(self):
+        """Wait for the context's work and report op codes the device rejected (tfhe_ctx_sync)."""
         self._check(self._lib.tfhe_ctx_sync(self._h))
+
+    def reserve(self, max_batch, with_mux=False):
+        """Pre-size the intermediate buffers (needed before capturing _dev calls into a graph)."""
+        self._check(self._lib.tfhe_ctx_reserve(self._h, int(max_batch), int(bool(with_mux))))
 
     def timing_enable(self, on=True):
         self._check(self._lib.tfhe_timing_enable(self._h, int(bool(on))))

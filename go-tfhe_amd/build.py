@@ -23,7 +23,9 @@ def _stale():
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into lib/libtfhe_hip.so (no-op when up to date)."""
     if not force and not _stale():
+        print(f"[build] {os.path.relpath(LIB_PATH)}: up to date with csrc/ (reused)")
         return LIB_PATH
+    print(f"[build] compiling {', '.join(x for x, _ in SOURCES)} for gfx950 -> {os.path.relpath(LIB_PATH)}", flush=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     procs = []

@@ -12,14 +12,23 @@ import numpy as np
 from ._binding import OPS
 
 
-def ripple_carry_adder(bits):
+def ripple_carry_adder(bits, fold_carry_in=True):
     """Wires: a[i] = i, b[i] = bits+i, sum[i] = 2*bits+i, carry-out = 3*bits.
-    Returns (levels, n_wires, sum_wires, carry_wire).  carry-in = Constant(false) is folded away
-    as in the reference example's first half adder: s0 = a0 XOR b0, c1 = a0 AND b0."""
+    Returns (levels, n_wires, sum_wires, carry_wire).
+
+    fold_carry_in=False is the circuit exactly as the reference writes it (README.md:78-106): `bits` FullAdders
+    of five gates each -- XOR(a,b), AND(a,b), AND(a^b, cin), XOR(a^b, cin), OR(a&b, (a^b)&cin) -- chained
+    from carry := gates.Constant(false): 5*bits gates (40 for 8 bits) in 1 + 2*bits levels (17).  The constant
+    lives on wire adder_constant_wire(bits); fill it with gates.Constant(False, params) (= the reference's
+    trivial sample with body 1 - 1/8 = 0xE0000001, gates.go:61-69) before running.
+
+    fold_carry_in=True (default) drops the three gates that only combine with that constant: s0 = a0 XOR b0,
+    c1 = a0 AND b0 -- 5*bits - 3 gates (37), 2*bits - 1 levels (15).  Same decrypted sums; sum[0] and the carries
+    are different ciphertexts (one bootstrap fewer on their path)."""
     a = lambda i: i
     b = lambda i: bits + i
     s = lambda i: 2 * bits + i
-    nxt = [3 * bits + 1]
+    nxt = [3 * bits + 2]                      # 3*bits + 1 is reserved for the constant-false wire
 
     def new():
         nxt[0] += 1
@@ -30,12 +39,12 @@ def ripple_carry_adder(bits):
     g = [new() for _ in range(bits)]          # a_i AND b_i
     lvl = []
     for i in range(bits):
-        lvl.append(("XOR", a(i), b(i), None, s(0) if i == 0 else x[i]))
-        # a 1-bit adder's carry-out IS a_0 AND b_0: route it to the carry wire directly
-        lvl.append(("AND", a(i), b(i), None, 3 * bits if bits == 1 else g[i]))
+        lvl.append(("XOR", a(i), b(i), None, s(0) if i == 0 and fold_carry_in else x[i]))
+        # folded: a 1-bit adder's carry-out IS a_0 AND b_0: route it to the carry wire directly
+        lvl.append(("AND", a(i), b(i), None, 3 * bits if bits == 1 and fold_carry_in else g[i]))
     levels.append(lvl)
-    carry = g[0]
-    for i in range(1, bits):
+    carry = g[0] if fold_carry_in else adder_constant_wire(bits)
+    for i in range(1 if fold_carry_in else 0, bits):
         t = new()
         # sum_i = x_i XOR c_i ; t = x_i AND c_i        (one level)
         levels.append([("XOR", x[i], carry, None, s(i)), ("AND", x[i], carry, None, t)])
@@ -44,6 +53,11 @@ def ripple_carry_adder(bits):
         levels.append([("OR", g[i], t, None, c_out)])
         carry = c_out
     return levels, nxt[0], [s(i) for i in range(bits)], 3 * bits
+
+
+def adder_constant_wire(bits):
+    """Wire that holds gates.Constant(false) for ripple_carry_adder(bits, fold_carry_in=False)."""
+    return 3 * bits + 1
 
 
 def count_gates(levels):
@@ -118,23 +132,39 @@ class CircuitExecutor:
             self._plan.append((ops, uniform, i0, i1, i2, out))
         self._op_cache = {}                      # (level, C) -> per-item op codes on the device
 
+    def capture(self, wires):
+        """Record run(wires) into a HIP graph (torch.cuda.CUDAGraph) and return it; replay() re-runs the whole
+        circuit on whatever the wire tensor holds at that time.  tfhe_gate_batch_dev only enqueues (no read-back,
+        no synchronisation), so the level loop captures as is; one un-captured run first sizes the context's
+        intermediate buffers and fills the op-code cache (neither may allocate during capture)."""
+        torch = self.torch
+        self.run(wires)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.run(wires)
+        return graph
+
     def run(self, wires, stream=None):
-        """wires: int32 tensor [n_wires][C][n+1] with the input wires filled; updated in place."""
+        """wires: int32 tensor [n_wires][C][n+1] with the input wires filled; updated in place.
+        Everything -- the operand gathers, the gate kernels and the result scatter -- is enqueued on `stream`
+        (default: torch's current stream), so the temporaries also belong to that stream's allocator pool."""
         torch = self.torch
         C = wires.shape[1]
         stream = stream or torch.cuda.current_stream()
-        for li, (ops, uniform, i0, i1, i2, out) in enumerate(self._plan):
-            G = i0.shape[0]
-            a = wires.index_select(0, i0).reshape(G * C, self.n1)
-            b = wires.index_select(0, i1).reshape(G * C, self.n1)
-            c = wires.index_select(0, i2).reshape(G * C, self.n1) if i2 is not None else None
-            res = torch.empty_like(a)
-            if uniform is not None:
-                self.ctx.gate_batch_dev(uniform, a, b, c, res, stream)
-            else:
-                op_t = self._op_cache.get((li, C))
-                if op_t is None:
-                    op_t = self._op_cache[(li, C)] = torch.from_numpy(np.repeat(ops, C)).to(a.device)
-                self.ctx.gate_batch_dev(op_t, a, b, c, res, stream)
-            wires.index_copy_(0, out, res.reshape(G, C, self.n1))
+        with torch.cuda.stream(stream):
+            for li, (ops, uniform, i0, i1, i2, out) in enumerate(self._plan):
+                G = i0.shape[0]
+                a = wires.index_select(0, i0).reshape(G * C, self.n1)
+                b = wires.index_select(0, i1).reshape(G * C, self.n1)
+                c = wires.index_select(0, i2).reshape(G * C, self.n1) if i2 is not None else None
+                res = torch.empty_like(a)
+                if uniform is not None:
+                    self.ctx.gate_batch_dev(uniform, a, b, c, res, stream)
+                else:
+                    op_t = self._op_cache.get((li, C))
+                    if op_t is None:
+                        op_t = self._op_cache[(li, C)] = torch.from_numpy(np.repeat(ops, C)).to(a.device)
+                    self.ctx.gate_batch_dev(op_t, a, b, c, res, stream)
+                wires.index_copy_(0, out, res.reshape(G, C, self.n1))
         return wires

@@ -24,9 +24,12 @@ class CloudKey:
         self.ctx.close()
 
     @classmethod
-    def NewCloudKey(cls, params, key_lv0, key_lv1, alpha_lv0, alpha_lv1, seed=0, device=0):
+    def NewCloudKey(cls, params, key_lv0, key_lv1, alpha_lv0, alpha_lv1, seed=None, device=0):
         """cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31) generated ON the GPU
-        (tfhe_keygen_cloud): nothing but the two binary secret keys crosses PCIe."""
+        (tfhe_keygen_cloud_seeded): nothing but the two binary secret keys crosses PCIe.
+        seed=None draws 128 bits from the OS entropy source, like the reference's auto-seeded generator; a fixed
+        integer seed makes the cloud key reproducible and is for tests only -- the seed is secret key material
+        (every mask and noise sample of the published key follows from it)."""
         ck = cls(params, device=device)
         ck.ctx.keygen_cloud(key_lv0, key_lv1, alpha_lv0, alpha_lv1, seed)
         return ck

@@ -19,16 +19,10 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
     // N = 1024, launches of up to quad_max items: four waves per bootstrap (kernels_quad.hpp)
     const int quad_max = a0.bskq ? quad_limit : 0;
     const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 4 : 2) * num_cus;
-    const size_t n1 = (size_t)a0.n + 1;
-    const size_t trl = shape_is_512(shape) ? 2 * 512 : shape_is_1024(shape) ? 2 * 1024 : 2 * 2048;
     for (int base = 0; base < B; base += cap) {
         const int cnt = B - base < cap ? B - base : cap;
         BlindRotateArgs a = a0;
-        a.in0 = a0.in0 + base * n1;
-        if (a0.in1) a.in1 = a0.in1 + base * n1;
-        if (a0.ops) a.ops = a0.ops + base;
-        a.tv = a0.tv + (size_t)base * a0.tv_stride;
-        a.out = a0.out + base * trl;
+        a.first = a0.first + base;
         a.batch = cnt;
         const dim3 g(cnt);
         if (shape_is_1024(shape) && cnt <= quad_max) {

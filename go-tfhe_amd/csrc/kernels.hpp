@@ -77,10 +77,67 @@ struct BlindRotateArgs {
     uint32_t *out;          // [B][2][N]
     int n, nsteps, Nbit;
     uint32_t offset;        // decomposition offset (cloudkey.go:60-71)
-    int batch;              // items in this launch (only read by kernels that put several items in a workgroup)
+    int first, batch;       // this launch covers items [first, first + batch) of the arrays above
     const cd *bskq;         // the same key in the four-wave layout (kernels_quad.hpp), N = 1024 shapes only
     const cd *twq;          // twiddle table of the four-wave kernel
+    // Device-side MUX split (gates.go:107-114; tfhe_hip.hip: gate_batch_device).  With idx != nullptr, item
+    // v < split is a direct item whose MUX op code reads as AND (pass A: AND(a,b)); item v >= split is entry
+    // k = v - split of the compact list idx[0 .. *count): first operand row idx[k] of in0, second operand row
+    // (list_in1_by_idx ? idx[k] : k) of list_in1, gate list_op.  Entries k >= *count do not exist: their
+    // workgroups exit at once (the host sizes launches for the worst case and never reads the count).
+    const int *idx;
+    const int *count;
+    int split;
+    const uint32_t *list_in1;
+    int list_in1_by_idx, list_op;
+    int *status;            // device word: bit 0 is set when a gate item carries an op code the launch cannot run
 };
+constexpr int kStatusBadOp = 1;
+
+// Whether item v of a launch exists (always, unless it is a list entry past the device-side count).
+__device__ __forceinline__ bool gate_item_live(const BlindRotateArgs &A, int v)
+{
+    return !A.idx || v < A.split || v - A.split < *A.count;
+}
+
+// Prologue shared by every blind-rotate kernel: gate linear preparation (gates_helper.go:10-63) and mod-switch of
+// the n+1 words of item v (evaluator.go:116,122) by threads tid, tid + nthreads, ... into abar[0..n) and bt.
+__device__ __forceinline__ void gate_prep_modswitch(const BlindRotateArgs &A, int v, int tid, int nthreads, int N,
+                                                    uint16_t *abar, int *bt)
+{
+    const int n = A.n;
+    size_t r0 = (size_t)v, r1 = (size_t)v;
+    const uint32_t *p1 = A.in1;
+    int op = A.ops ? (int)A.ops[v < A.split || !A.idx ? v : 0] : A.op_uniform;
+    if (A.idx) {
+        if (v < A.split) {
+            if (op == 10) op = 1;                       // TFHE_OP_MUX -> TFHE_OP_AND on (a, b)
+        } else {
+            const int k = v - A.split;
+            r0 = (size_t)A.idx[k];
+            r1 = A.list_in1_by_idx ? r0 : (size_t)k;
+            p1 = A.list_in1;
+            op = A.list_op;
+        }
+    }
+    // a two-operand launch only knows the ten binary gates (MUX exists as the three passes of the list form):
+    // anything else is recorded for tfhe_ctx_sync and runs as a plain bootstrap of the first operand
+    if (p1 && (op < 0 || op > 9) && tid == 0 && A.status) atomicOr(A.status, kStatusBadOp);
+    const GateCoef g = gate_coef(p1 ? op : -1);
+    const uint32_t *x0 = A.in0 + r0 * (n + 1);
+    const uint32_t *x1 = p1 ? p1 + r1 * (n + 1) : x0;
+    const int sh = 32 - A.Nbit - 1;
+    const uint32_t rnd = 1u << (sh - 1);
+    for (int x = tid; x <= n; x += nthreads) {
+        uint32_t w = g.sa * x0[x] + (p1 ? g.sb * x1[x] : 0u);
+        if (x == n) {
+            w += g.cst;
+            *bt = 2 * N - (int)(((unsigned long long)w + rnd) >> sh);     // int add, no 32-bit wrap (evaluator.go:116)
+        } else {
+            abar[x] = (uint16_t)((uint32_t)(w + rnd) >> sh);               // wraps (evaluator.go:122)
+        }
+    }
+}
 
 constexpr int kMaxLweDim = 1280;      // Uint7/8 use n = 1160 (params.go:444-510)
 
@@ -220,30 +277,17 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
     uint32_t (&accL)[2][N] = accAll[grp];
     uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
     int &btL = btAll[grp];
-    int item = blockIdx.x * ITEMS + grp;
-    const bool live = ITEMS == 1 || item < A.batch;        // ragged batch: idle pairs recompute the last item, store nothing
-    if (!live) item = A.batch - 1;
+    // items of this workgroup: [first + blockIdx.x*ITEMS, ...); the live ones form a prefix (ragged batch, or
+    // list entries past the device-side count): idle pairs recompute the workgroup's first item and store nothing
+    const int wg_first = A.first + blockIdx.x * ITEMS;
+    if (!gate_item_live(A, wg_first)) return;
+    int item = wg_first + grp;
+    const bool live = ITEMS == 1 || (blockIdx.x * ITEMS + grp < A.batch && gate_item_live(A, item));
+    if (!live) item = wg_first;
     const int n = A.n;
 
     // ---- gate linear prep + mod-switch (gates_helper.go:10-63, evaluator.go:116,122)
-    {
-        const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
-        const GateCoef g = gate_coef(A.in1 ? op : -1);
-        const uint32_t *x0 = A.in0 + (size_t)item * (n + 1);
-        const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
-        const int sh = 32 - A.Nbit - 1;
-        const uint32_t rnd = 1u << (sh - 1);
-        for (int x = tid; x <= n; x += 128) {
-            uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
-            if (x == n) {
-                v += g.cst;
-                // int add, no 32-bit wrap (evaluator.go:116)
-                btL = 2 * N - (int)(((unsigned long long)v + rnd) >> sh);
-            } else {
-                abarL[x] = (uint16_t)((uint32_t)(v + rnd) >> sh);   // wraps (evaluator.go:122)
-            }
-        }
-    }
+    gate_prep_modswitch(A, item, tid, 128, N, abarL, &btL);
     LaneTwiddles tw;
     load_lane_twiddles(tw, A.tw, lane);
     __syncthreads();
@@ -381,7 +425,14 @@ struct KeySwitchArgs {
     const uint32_t *ksk;     // packed
     uint32_t *out;           // [B][n+1]
     int n, N, t, basebit, n1p;
+    const int *count;        // optional device-side item count (list launches): only min(B, *count) items exist
 };
+__device__ __forceinline__ int ks_items(const KeySwitchArgs &A, int B)
+{
+    if (!A.count) return B;
+    const int c = *A.count;
+    return c < B ? c : B;
+}
 
 template <int CH, typename IdxT>
 __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
@@ -392,6 +443,7 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
     __shared__ int count;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int N = A.N, t = A.t, bb = A.basebit, base1 = (1 << bb) - 1;
+    if (A.count && (int)blockIdx.x >= *A.count) return;
     const uint32_t *ta = A.trlwe + (size_t)blockIdx.x * 2 * N;
     if (tid == 0) count = 0;
     __syncthreads();
@@ -451,9 +503,11 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
 // ranges are combined with 32-bit atomic adds into `out`, which k_ks_init has set to (0, ..., 0, b)
 // (keyswitch.go:18-21).
 // ------------------------------------------------------------------------------------
-static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B)
+static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B,
+                                 const int *__restrict__ count)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (count && *count < B) B = *count;
     if (idx >= (size_t)B * (n + 1)) return;
     const int b = (int)(idx / (n + 1)), x = (int)(idx % (n + 1));
     out[idx] = x == n ? trlwe[(size_t)b * 2 * N + N] : 0u;
@@ -473,6 +527,7 @@ __global__ __launch_bounds__(64) void k_keyswitch_pair(KeySwitchArgs A, int B, i
 {
     __shared__ uint4 comb[16][64];
     const int lane = threadIdx.x;
+    B = ks_items(A, B);
     const int N = A.N, t = A.t;                       // basebit = 2
     int tx, ty;
     {
@@ -481,6 +536,7 @@ __global__ __launch_bounds__(64) void k_keyswitch_pair(KeySwitchArgs A, int B, i
         else { tx = id % ct_tiles; ty = id / ct_tiles; }
     }
     const int b0 = tx * T, q0 = (ty % col_slices) * 64 + lane, i0 = (ty / col_slices) * IC;
+    if (b0 >= B) return;
     const int quads = A.n1p >> 2;
     const bool active = q0 < quads;
     const uint32_t prec = 1u << (32 - (1 + 2 * t));
@@ -564,6 +620,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = A.N, t = A.t;
+    B = ks_items(A, B);
     // 1-D grid, XCD-aware decode: hardware deals workgroup ids round-robin over the 8 XCDs (each with its own
     // L2), so the ciphertext tiles that share the key rows of one (column block, coefficient range) are placed
     // on the SAME XCD, consecutive in time -- the rows then come from HBM once instead of once per tile
@@ -574,6 +631,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
         tile_x = slot % ct_tiles; tile_cr = (slot / ct_tiles) * 8 + xcd;
     }
     const int b0 = tile_x * 256 + w * 64, c0 = (tile_cr % col_blocks) * C, i0 = (tile_cr / col_blocks) * IC;
+    if (tile_x * 256 >= B) return;                    // whole workgroup (the barriers below are workgroup-wide)
     const uint32_t prec = 1u << (32 - (1 + BB * t));
     const int wshift = 32 - BB * t;
     if (tid < C) rowbuf[0][0][tid] = rowbuf[1][0][tid] = 0u;
@@ -698,19 +756,88 @@ static __global__ __launch_bounds__(64) void k_to_poly(const double *__restrict_
 
 // Small helpers for the MUX composition (gates.go:107-114): gather / scatter LWE samples.
 static __global__ void k_gather_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
-                              int n1, int count)
+                              int n1, const int *__restrict__ count)
 {
     const int r = blockIdx.x;
-    if (r >= count) return;
+    if (r >= *count) return;
     for (int x = threadIdx.x; x < n1; x += blockDim.x) dst[(size_t)r * n1 + x] = src[(size_t)idx[r] * n1 + x];
 }
 
 static __global__ void k_scatter_rows(const uint32_t *__restrict__ src, const int *__restrict__ idx, uint32_t *__restrict__ dst,
-                               int n1, int count)
+                               int n1, const int *__restrict__ count)
 {
     const int r = blockIdx.x;
-    if (r >= count) return;
+    if (r >= *count) return;
     for (int x = threadIdx.x; x < n1; x += blockDim.x) dst[(size_t)idx[r] * n1 + x] = src[(size_t)r * n1 + x];
+}
+
+// ------------------------------------------------------------------------------------
+// Device-side MUX split (gates.go:107-114): the compact, ascending list of the items whose op code is MUX,
+// built without the host ever seeing the op codes.  Three launches: per-block counts, one-block scan, fill.
+// ------------------------------------------------------------------------------------
+constexpr int kPlanBlock = 1024;                 // items per block (256 threads x 4)
+
+__device__ __forceinline__ int plan_block_scan(int mine, int *sh /* [256] */, int tid)
+{
+    sh[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int v = tid >= d ? sh[tid - d] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    return sh[tid] - mine;                        // exclusive prefix; sh[255] = block total
+}
+
+static __global__ __launch_bounds__(256) void k_mux_count(const uint8_t *__restrict__ ops, int B, int *__restrict__ block_counts,
+                                                          int *__restrict__ status)
+{
+    __shared__ int sh[256];
+    const int tid = threadIdx.x, base = blockIdx.x * kPlanBlock + tid * 4;
+    int mine = 0, bad = 0;
+    for (int k = 0; k < 4; k++)
+        if (base + k < B) { const int op = ops[base + k]; mine += op == 10; bad |= op > 10; }
+    if (bad) atomicOr(status, kStatusBadOp);
+    plan_block_scan(mine, sh, tid);
+    if (tid == 0) block_counts[blockIdx.x] = sh[255];
+}
+
+// offsets[b] = sum of block_counts[0..b), offsets[nb] = total = *count.
+static __global__ __launch_bounds__(256) void k_mux_scan(const int *__restrict__ block_counts, int nb, int *__restrict__ offsets,
+                                                         int *__restrict__ count)
+{
+    __shared__ int sh[256];
+    const int tid = threadIdx.x;
+    int carry = 0;
+    for (int base = 0; base < nb; base += 256) {
+        const int mine = base + tid < nb ? block_counts[base + tid] : 0;
+        const int ex = plan_block_scan(mine, sh, tid);
+        if (base + tid < nb) offsets[base + tid] = carry + ex;
+        carry += sh[255];
+        __syncthreads();
+    }
+    if (tid == 0) { offsets[nb] = carry; *count = carry; }
+}
+
+static __global__ __launch_bounds__(256) void k_mux_fill(const uint8_t *__restrict__ ops, int B, const int *__restrict__ offsets,
+                                                         int *__restrict__ idx)
+{
+    __shared__ int sh[256];
+    const int tid = threadIdx.x, base = blockIdx.x * kPlanBlock + tid * 4;
+    int mine = 0;
+    for (int k = 0; k < 4; k++) mine += base + k < B && ops[base + k] == 10;
+    int at = offsets[blockIdx.x] + plan_block_scan(mine, sh, tid);
+    for (int k = 0; k < 4; k++)
+        if (base + k < B && ops[base + k] == 10) idx[at++] = base + k;
+}
+
+// every item is a MUX: idx = 0..B-1, *count = B
+static __global__ void k_mux_all(int B, int *__restrict__ idx, int *__restrict__ count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) idx[i] = i;
+    if (i == 0) *count = B;
 }
 
 } // namespace tfhe

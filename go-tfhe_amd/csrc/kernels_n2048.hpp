@@ -213,27 +213,13 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
     uint32_t (&accL)[2][N] = accAll[grp];
     uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
     int &btL = btAll[grp];
-    int item = blockIdx.x * ITEMS + grp;
-    const bool live = ITEMS == 1 || item < A.batch;
-    if (!live) item = A.batch - 1;                 // ragged batch: the idle group recomputes the last item, stores nothing
+    const int wg_first = A.first + blockIdx.x * ITEMS;
+    if (!gate_item_live(A, wg_first)) return;       // list entries past the device-side count (kernels.hpp)
+    int item = wg_first + grp;
+    const bool live = ITEMS == 1 || (blockIdx.x * ITEMS + grp < A.batch && gate_item_live(A, item));
+    if (!live) item = wg_first;                     // the idle group recomputes the first item, stores nothing
     const int n = A.n;
-    {
-        const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
-        const GateCoef g = gate_coef(A.in1 ? op : -1);
-        const uint32_t *x0 = A.in0 + (size_t)item * (n + 1);
-        const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
-        const int sh = 32 - A.Nbit - 1;
-        const uint32_t rnd = 1u << (sh - 1);
-        for (int x = tid; x <= n; x += 256) {
-            uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
-            if (x == n) {
-                v += g.cst;
-                btL = 2 * N - (int)(((unsigned long long)v + rnd) >> sh);
-            } else {
-                abarL[x] = (uint16_t)((uint32_t)(v + rnd) >> sh);
-            }
-        }
-    }
+    gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
     LaneTwiddles tw;
     const cd *table = A.tw + (size_t)h * kTwCount1024;
     load_lane_twiddles(tw, table, lane);

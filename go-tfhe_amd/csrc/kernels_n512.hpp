@@ -210,25 +210,9 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate_512(BlindRotateArgs A)
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
-    const int item = blockIdx.x;
-    const int n = A.n;
-    {
-        const int op = A.ops ? (int)A.ops[item] : A.op_uniform;
-        const GateCoef g = gate_coef(A.in1 ? op : -1);
-        const uint32_t *x0 = A.in0 + (size_t)item * (n + 1);
-        const uint32_t *x1 = A.in1 ? A.in1 + (size_t)item * (n + 1) : x0;
-        const int sh = 32 - A.Nbit - 1;
-        const uint32_t rnd = 1u << (sh - 1);
-        for (int x = lane; x <= n; x += 64) {
-            uint32_t v = g.sa * x0[x] + (A.in1 ? g.sb * x1[x] : 0u);
-            if (x == n) {
-                v += g.cst;
-                btL = 2 * N - (int)(((unsigned long long)v + rnd) >> sh);   // b~: no 32-bit wrap (evaluator.go:113)
-            } else {
-                abarL[x] = (uint16_t)((uint32_t)(v + rnd) >> sh);              // a~: wraps (evaluator.go:121)
-            }
-        }
-    }
+    const int item = A.first + blockIdx.x;
+    if (!gate_item_live(A, item)) return;           // list entries past the device-side count (kernels.hpp)
+    gate_prep_modswitch(A, item, lane, 64, N, abarL, &btL);
     LaneTwiddles512 tw;
     load_lane_twiddles_512(tw, A.tw, hl);
     __syncthreads();

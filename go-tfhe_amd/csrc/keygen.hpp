@@ -9,7 +9,10 @@
 // Randomness: the reference draws from an auto-seeded math/rand (no reproducible seed exists,
 // SURVEY.md 3.4); here a counter-based Philox4x32-10 keyed by (seed, stream) gives every sample a
 // fixed position, so a (seed, secret key) pair always produces the same cloud key regardless of
-// launch geometry.  Gaussians by Box-Muller in fp64, added on the torus exactly as
+// launch geometry.  The seed is SECRET key material: masks and noise of the published cloud key are a
+// function of it (whoever knows it can strip the noise and solve for the secret keys), so callers pass 128 bits
+// from the OS entropy source (tfhe_keygen_cloud_seeded with seed = NULL does) and fixed seeds only in tests.
+// Like the reference's math/rand, Philox is a statistical generator, not a cryptographic one.  Gaussians by Box-Muller in fp64, added on the torus exactly as
 // utils.GaussianTorus does (utils/utils.go:31-41: F64ToTorus(normal * stddev)).
 #pragma once
 
@@ -18,6 +21,12 @@
 #include "kernels_n512.hpp"
 
 namespace tfhe {
+
+// 128 bits of seed: lo keys the cipher, hi is folded into the two counter words that do not carry the sample
+// index (hi = 0 reproduces the 64-bit-seed streams of tfhe_keygen_cloud).
+struct Seed128 {
+    uint64_t lo, hi;
+};
 
 struct Philox {
     uint32_t key[2];
@@ -32,10 +41,10 @@ struct Philox {
         k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
     }
     // 4 random words for (seed, stream, index)
-    __device__ __forceinline__ static void block(uint64_t seed, uint32_t stream, uint64_t index, uint32_t (&out)[4])
+    __device__ __forceinline__ static void block(Seed128 seed, uint32_t stream, uint64_t index, uint32_t (&out)[4])
     {
-        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-        uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), stream, 0x7F4E0000u};
+        uint32_t k[2] = {(uint32_t)seed.lo, (uint32_t)(seed.lo >> 32)};
+        uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), stream ^ (uint32_t)seed.hi, 0x7F4E0000u ^ (uint32_t)(seed.hi >> 32)};
 #pragma unroll
         for (int r = 0; r < 10; r++) round(c, k);
         out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
@@ -49,7 +58,7 @@ __device__ __forceinline__ uint32_t f64_to_torus_small(double d)
 }
 
 // One uniform torus word and one Gaussian torus sample (mean 0, stddev alpha) per call.
-__device__ __forceinline__ void uniform_and_gaussian(uint64_t seed, uint32_t stream, uint64_t index, double alpha,
+__device__ __forceinline__ void uniform_and_gaussian(Seed128 seed, uint32_t stream, uint64_t index, double alpha,
                                                      uint32_t &uni, uint32_t &gauss)
 {
     uint32_t r[4];
@@ -61,7 +70,7 @@ __device__ __forceinline__ void uniform_and_gaussian(uint64_t seed, uint32_t str
     gauss = f64_to_torus_small(fmod(nrm * alpha, 1.0));
 }
 
-__device__ __forceinline__ uint32_t uniform_word(uint64_t seed, uint32_t stream, uint64_t index)
+__device__ __forceinline__ uint32_t uniform_word(Seed128 seed, uint32_t stream, uint64_t index)
 {
     uint32_t r[4];
     Philox::block(seed, stream, index, r);
@@ -75,7 +84,7 @@ constexpr uint32_t kStreamBskA = 1, kStreamKsk = 2;
 template <int L, int BGBIT>
 static __global__ __launch_bounds__(64) void k_keygen_bsk(cd *__restrict__ bsk, const cd *__restrict__ twt,
                                                            const cd *__restrict__ s1_spec /* [8][64] */,
-                                                           const uint32_t *__restrict__ s0, double alpha, uint64_t seed)
+                                                           const uint32_t *__restrict__ s0, double alpha, Seed128 seed)
 {
     __shared__ cd sc[kScratchSlots];
     const int lane = threadIdx.x;
@@ -143,7 +152,7 @@ static __global__ __launch_bounds__(64) void k_keygen_s1_spectrum(const uint32_t
 template <int BGBIT>
 static __global__ __launch_bounds__(64) void k_keygen_bsk_512(cd *__restrict__ bsk, const cd *__restrict__ twt,
                                                                const cd *__restrict__ s1_spec /* [8][32] */,
-                                                               const uint32_t *__restrict__ s0, double alpha, uint64_t seed)
+                                                               const uint32_t *__restrict__ s0, double alpha, Seed128 seed)
 {
     __shared__ cd sc[kScratchSlots];
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
@@ -189,7 +198,7 @@ static __global__ __launch_bounds__(64) void k_keygen_bsk_512(cd *__restrict__ b
 template <int BGBIT>
 static __global__ __launch_bounds__(64) void k_keygen_bsk_2048(cd *__restrict__ bsk, const cd *__restrict__ twt,
                                                                 const cd *__restrict__ s1_spec /* [16][64] */,
-                                                                const uint32_t *__restrict__ s0, double alpha, uint64_t seed)
+                                                                const uint32_t *__restrict__ s0, double alpha, Seed128 seed)
 {
     __shared__ cd sc[kScratchSlots];
     const int lane = threadIdx.x;
@@ -251,7 +260,7 @@ static __global__ __launch_bounds__(64) void k_keygen_s1_spectrum_2048(const uin
 //      k * s1[i] / 2^((j+1)*basebit)   (cloudkey.go:107-112), an exact torus shift.
 static __global__ __launch_bounds__(64) void k_keygen_ksk(uint32_t *__restrict__ ksk, const uint32_t *__restrict__ s0,
                                                            const uint32_t *__restrict__ s1, int n, int n1p, int t, int bb,
-                                                           size_t rows_packed, double alpha, uint64_t seed)
+                                                           size_t rows_packed, double alpha, Seed128 seed)
 {
     const int lane = threadIdx.x;
     const size_t row = blockIdx.x;

@@ -6,6 +6,7 @@
 #include "../../include/tfhe_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/random.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -81,6 +82,8 @@ struct tfhe_ctx {
     uint32_t offset = 0;        // cloudkey.go:60-71
     int n1p = 0;                // padded LWE row length of the packed KSK
     int num_cus = 256;          // hipDeviceProp_t.multiProcessorCount
+    hipStream_t last_dev_stream = nullptr;      // stream of the most recent _dev call (tfhe_ctx_sync waits for it too)
+    bool last_dev_stream_set = false;
     int quad_limit = 0;         // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
     hipStream_t stream = nullptr;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -90,11 +93,12 @@ struct tfhe_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev[2];
     std::vector<hipEvent_t> ev_pool;
     DevBuf bsk, ksk, tw, gate_tv;
+    DevBuf status;              // one int: kStatus* bits set by kernels (bad op codes on the _dev path)
     DevBuf bskq, twq;           // four-wave layout of the key + its twiddles (N = 1024 shapes, kernels_quad.hpp)
     bool have_bsk = false, have_ksk = false;
     // staging (grow-only)
-    DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_t0, s_t1, s_t2, s_t3;
-    std::mutex mu;
+    DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_plan, s_t0, s_t1, s_t2, s_t3;
+    std::recursive_mutex mu;    // host-pointer calls hold it for their whole duration, _dev calls while they reserve and enqueue
 };
 
 namespace {
@@ -184,9 +188,18 @@ std::vector<cd> make_twiddles_quad()
     return t;
 }
 
-// Event pair bracketing one launch of kernel `which` on stream st.
+// Event pair bracketing one launch of kernel `which` on stream st.  Nothing is recorded while the stream is being
+// captured into a hipGraph (the events would belong to the graph, not to this context).
+bool stream_capturing(hipStream_t st)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 int timing_begin(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t *stop)
 {
+    *stop = nullptr;
+    if (stream_capturing(st)) return TFHE_OK;
     hipEvent_t a, b;
     if (c->timing) {
         for (hipEvent_t *e : {&a, &b}) {
@@ -199,6 +212,14 @@ int timing_begin(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t *stop)
     }
     HIP_TRY(hipEventRecord(a, st));
     *stop = b;
+    return TFHE_OK;
+}
+
+int timing_end(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t stop)
+{
+    if (!stop) return TFHE_OK;
+    HIP_TRY(hipEventRecord(stop, st));
+    c->ev_valid[which] = !c->timing;
     return TFHE_OK;
 }
 
@@ -222,40 +243,57 @@ int make_quad_key(tfhe_ctx *c, hipStream_t st)
     return TFHE_OK;
 }
 
-int launch_blind_rotate(tfhe_ctx *c, const uint32_t *d_in0, const uint32_t *d_in1, const uint8_t *d_ops,
-                        int op_uniform, const uint32_t *d_tv, int tv_per_item, uint32_t *d_out, int B, int nsteps,
-                        hipStream_t st)
+// Items of one blind-rotate request (see BlindRotateArgs): direct operands, or the list form of the MUX passes.
+struct RotateJob {
+    const uint32_t *in0 = nullptr, *in1 = nullptr;
+    const uint8_t *ops = nullptr;
+    int op_uniform = -1;
+    const uint32_t *tv = nullptr;
+    int tv_per_item = 0;
+    uint32_t *out = nullptr;
+    int first = 0, B = 0, nsteps = -1;
+    const int *idx = nullptr, *count = nullptr;
+    int split = 0;
+    const uint32_t *list_in1 = nullptr;
+    int list_in1_by_idx = 0, list_op = 0;
+};
+
+int launch_blind_rotate(tfhe_ctx *c, const RotateJob &j, hipStream_t st)
 {
     if (!c->have_bsk) return fail(TFHE_E_NOKEY, "bootstrapping key not loaded");
-    if (B <= 0) return TFHE_OK;
+    if (j.B <= 0) return TFHE_OK;
     BlindRotateArgs a{};
     a.bsk = c->bsk.as<cd>();
     a.tw = c->tw.as<cd>();
     a.bskq = c->bskq.as<cd>(); a.twq = c->twq.as<cd>();
-    a.in0 = d_in0; a.in1 = d_in1; a.ops = d_ops; a.op_uniform = op_uniform;
-    a.tv = d_tv ? d_tv : c->gate_tv.as<uint32_t>();
-    a.tv_stride = (d_tv && tv_per_item) ? 2L * c->P.N : 0;
-    a.out = d_out;
+    a.in0 = j.in0; a.in1 = j.in1; a.ops = j.ops; a.op_uniform = j.op_uniform;
+    a.tv = j.tv ? j.tv : c->gate_tv.as<uint32_t>();
+    a.tv_stride = (j.tv && j.tv_per_item) ? 2L * c->P.N : 0;
+    a.out = j.out;
     a.n = c->P.n; a.Nbit = c->P.Nbit;
-    a.nsteps = (nsteps < 0 || nsteps > c->P.n) ? c->P.n : nsteps;
+    a.nsteps = (j.nsteps < 0 || j.nsteps > c->P.n) ? c->P.n : j.nsteps;
     a.offset = c->offset;
+    a.first = j.first;
+    a.idx = j.idx; a.count = j.count; a.split = j.split;
+    a.list_in1 = j.list_in1; a.list_in1_by_idx = j.list_in1_by_idx; a.list_op = j.list_op;
+    a.status = c->status.as<int>();
     hipEvent_t stop;
     int trc = timing_begin(c, 0, st, &stop);
     if (trc) return trc;
-    launch_blind_rotate(c->shape, a, B, c->num_cus, c->quad_limit, st);
+    launch_blind_rotate(c->shape, a, j.B, c->num_cus, c->quad_limit, st);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(stop, st));
-    c->ev_valid[0] = !c->timing;
-    return TFHE_OK;
+    return timing_end(c, 0, st, stop);
 }
 
-int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int B, hipStream_t st)
+// d_count: optional device-side item count (list launches); B is then the worst case the grids are sized for.
+int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int B, const int *d_count, hipStream_t st)
 {
     if (!c->have_ksk) return fail(TFHE_E_NOKEY, "key-switching key not loaded");
     if (B <= 0) return TFHE_OK;
     KeySwitchArgs a{};
     a.trlwe = d_trlwe; a.ksk = c->ksk.as<uint32_t>(); a.out = d_out;
     a.n = c->P.n; a.N = c->P.N; a.t = c->P.t; a.basebit = c->P.basebit; a.n1p = c->n1p;
+    a.count = d_count;
     const int ch = (c->n1p + 255) / 256;
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
@@ -270,13 +308,11 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         while (ranges * 16 <= c->P.N && ct_tiles * col_slices * ranges < 6 * c->num_cus) ranges *= 2;
         const int IC = c->P.N / ranges;
         const size_t tot = (size_t)B * (c->P.n + 1);
-        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
         hipLaunchKernelGGL((k_keyswitch_pair<kT>), dim3((unsigned)(ct_tiles * col_slices * ranges)), dim3(64), 0, st, a, B, IC,
                            ct_tiles, col_slices);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(stop, st));
-        c->ev_valid[1] = !c->timing;
-        return TFHE_OK;
+        return timing_end(c, 1, st, stop);
     }
     // larger bases (Uint sets), batches that fill at least one wave of ciphertexts: column-sliced tiles
     if (c->P.basebit >= 4 && c->P.basebit <= 7 && B >= 64) {
@@ -285,7 +321,7 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         while (ranges * 8 < c->P.N && ct_tiles * col_blocks * ranges < 4 * c->num_cus) ranges *= 2;
         const int IC = c->P.N / ranges;
         const size_t tot = (size_t)B * (c->P.n + 1);
-        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B);
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
         const dim3 g((unsigned)(ct_tiles * col_blocks * ranges));
         switch (c->P.basebit) {
         case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
@@ -294,9 +330,7 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(stop, st));
-        c->ev_valid[1] = !c->timing;
-        return TFHE_OK;
+        return timing_end(c, 1, st, stop);
     }
     // row indices fit 16 bits for the 2-bit key-switch base of the N=1024 sets (halves the LDS list)
     const bool small_idx = ksk_rows_packed(c->P) < 65535;
@@ -313,68 +347,118 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     }
 #undef KS_LAUNCH
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(stop, st));
-    c->ev_valid[1] = !c->timing;
+    return timing_end(c, 1, st, stop);
+}
+
+// Device work is issued in slabs of at most this many items, so the context's intermediate buffers have a fixed
+// size (16 co-resident launches' worth: 268 MB of TRLWE samples at N = 1024 with the MUX passes) however large
+// the batch -- after the first large call nothing is ever re-allocated under work in flight.
+int slab_items(const tfhe_ctx *c) { return 16 * (shape_is_512(c->shape) ? 8 : shape_is_1024(c->shape) ? 4 : 2) * c->num_cus; }
+
+// Scratch for slabs of up to `items` bootstraps (mux: with the three-pass MUX form).  hipMalloc is not allowed
+// while a stream is being captured: callers that capture run one call (or tfhe_ctx_reserve) beforehand.
+int reserve_scratch(tfhe_ctx *c, int items, bool mux)
+{
+    const int S = items < slab_items(c) ? items : slab_items(c);
+    const size_t trl = (size_t)S * 2 * c->P.N * sizeof(uint32_t), rows = (size_t)S * (c->P.n + 1) * sizeof(uint32_t);
+    int rc;
+    if ((rc = c->s_trlwe.reserve(mux ? 2 * trl : trl))) return rc;
+    if (mux) {
+        const int nb = (S + kPlanBlock - 1) / kPlanBlock;
+        if ((rc = c->s_idx.reserve((size_t)S * sizeof(int))) || (rc = c->s_plan.reserve((size_t)(2 * nb + 2) * sizeof(int))) ||
+            (rc = c->s_t0.reserve(rows)) || (rc = c->s_t1.reserve(rows)))
+            return rc;
+    }
     return TFHE_OK;
 }
 
-// Full gate batch on device pointers; handles MUX = OR(AND(a,b), ANDNY(a,c)) (gates.go:107-114:
-// AND(NOT a, c) has exactly ANDNY's linear form -a + c - 1/8).  h_ops may be nullptr.
-int gate_batch_device(tfhe_ctx *c, const uint8_t *d_ops, const uint8_t *h_ops, int op_uniform, const uint32_t *d_a,
-                      const uint32_t *d_b, const uint32_t *d_c, uint32_t *d_out, int B, hipStream_t st)
+// Full gate batch on device pointers, enqueue-only.  MUX = OR(AND(a,b), AND(NOT a, c)) (gates.go:107-114;
+// AND(NOT a, c) has exactly ANDNY's linear form -a + c - 1/8) in two bootstrap passes:
+//   plan    compact list of the MUX items, built on the device (k_mux_*; all items when op_uniform = MUX)
+//   pass 1  ONE blind-rotate request over S + Mx items: item v < S runs its own gate (MUX reads as AND(a,b)),
+//           list entry k runs ANDNY(a[idx k], c[idx k]); key switch to out (first S) and to y (entries)
+//   pass 2  OR(out[idx k], y[k]) over the list, scattered back to out[idx k]
+// The host never learns Mx: list launches are sized for the worst case and the workgroups of entries past the
+// device-side count exit at once.  Without a third operand no item can be a MUX and only pass 1's first half runs.
+int gate_batch_device(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a, const uint32_t *d_b,
+                      const uint32_t *d_c, uint32_t *d_out, int B, hipStream_t st)
 {
-    const int n1 = c->P.n + 1;
-    const size_t trl = (size_t)B * 2 * c->P.N * sizeof(uint32_t);
-    std::vector<int> mux;
-    if (d_ops) {
-        for (int i = 0; i < B; i++) {
-            if (h_ops[i] > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d at item %d", h_ops[i], i);
-            if (h_ops[i] == TFHE_OP_MUX) mux.push_back(i);
-        }
-    } else {
-        if (op_uniform < 0 || op_uniform > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d", op_uniform);
-        if (op_uniform == TFHE_OP_MUX) { mux.resize(B); for (int i = 0; i < B; i++) mux[i] = i; }
-    }
-    if (!mux.empty() && !d_c) return fail(TFHE_E_INVALID, "MUX needs the third operand");
+    if (!d_ops && (op_uniform < 0 || op_uniform > TFHE_OP_MUX)) return fail(TFHE_E_INVALID, "bad op code %d", op_uniform);
+    const bool mux = d_c && (d_ops || op_uniform == TFHE_OP_MUX);
+    if (!d_ops && op_uniform == TFHE_OP_MUX && !d_c) return fail(TFHE_E_INVALID, "MUX needs the third operand");
     int rc;
-    if ((rc = c->s_trlwe.reserve(trl))) return rc;
-    // pass A: every item with op' = (MUX ? AND : op) on (a, b)
-    const uint8_t *opsA = d_ops;
-    int uniA = op_uniform;
-    if (!mux.empty()) {
-        if (d_ops) {
-            std::vector<uint8_t> tmp(h_ops, h_ops + B);
-            for (int i : mux) tmp[i] = TFHE_OP_AND;
-            if ((rc = c->s_t3.reserve(B))) return rc;
-            HIP_TRY(hipMemcpyAsync(c->s_t3.p, tmp.data(), B, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));      // tmp goes out of scope
-            opsA = c->s_t3.as<uint8_t>();
-        } else {
-            uniA = TFHE_OP_AND;
+    if ((rc = reserve_scratch(c, B, mux))) return rc;
+    const size_t n1 = (size_t)c->P.n + 1, trlw = (size_t)2 * c->P.N;
+    const int slab = slab_items(c);
+    for (int base = 0; base < B; base += slab) {
+        const int S = B - base < slab ? B - base : slab;
+        const uint8_t *ops = d_ops ? d_ops + base : nullptr;
+        const uint32_t *a = d_a + base * n1, *b = d_b + base * n1, *cc = d_c ? d_c + base * n1 : nullptr;
+        uint32_t *out = d_out + base * n1, *trl = c->s_trlwe.as<uint32_t>();
+        RotateJob j;
+        j.in0 = a; j.in1 = b; j.ops = ops; j.op_uniform = op_uniform; j.out = trl; j.B = S;
+        if (!mux) {
+            if ((rc = launch_blind_rotate(c, j, st)) || (rc = launch_keyswitch(c, trl, out, S, nullptr, st))) return rc;
+            continue;
         }
+        int *idx = c->s_idx.as<int>(), *plan = c->s_plan.as<int>();
+        const int nb = (S + kPlanBlock - 1) / kPlanBlock;
+        int *count = plan + 2 * nb + 1;                    // plan: [nb] block counts, [nb + 1] offsets, count
+        if (ops) {
+            hipLaunchKernelGGL(k_mux_count, dim3(nb), dim3(256), 0, st, ops, S, plan, c->status.as<int>());
+            hipLaunchKernelGGL(k_mux_scan, dim3(1), dim3(256), 0, st, (const int *)plan, nb, plan + nb, count);
+            hipLaunchKernelGGL(k_mux_fill, dim3(nb), dim3(256), 0, st, ops, S, (const int *)(plan + nb), idx);
+        } else {
+            hipLaunchKernelGGL(k_mux_all, dim3((S + 255) / 256), dim3(256), 0, st, S, idx, count);
+        }
+        uint32_t *y = c->s_t0.as<uint32_t>(), *z = c->s_t1.as<uint32_t>();
+        // pass 1: S direct items + up to S list entries in one request
+        j.B = 2 * S; j.idx = idx; j.count = count; j.split = S;
+        j.list_in1 = cc; j.list_in1_by_idx = 1; j.list_op = TFHE_OP_ANDNY;
+        if ((rc = launch_blind_rotate(c, j, st))) return rc;
+        if ((rc = launch_keyswitch(c, trl, out, S, nullptr, st))) return rc;
+        if ((rc = launch_keyswitch(c, trl + (size_t)S * trlw, y, S, count, st))) return rc;
+        // pass 2: OR(out[idx k], y[k]) -> z[k] -> out[idx k]
+        RotateJob o;
+        o.in0 = out; o.in1 = out; o.op_uniform = TFHE_OP_OR; o.out = trl; o.B = S;
+        o.idx = idx; o.count = count; o.split = 0; o.list_in1 = y; o.list_in1_by_idx = 0; o.list_op = TFHE_OP_OR;
+        if ((rc = launch_blind_rotate(c, o, st))) return rc;
+        if ((rc = launch_keyswitch(c, trl, z, S, count, st))) return rc;
+        hipLaunchKernelGGL(k_scatter_rows, dim3(S), dim3(256), 0, st, (const uint32_t *)z, (const int *)idx, out, (int)n1,
+                           (const int *)count);
+        HIP_TRY(hipGetLastError());
     }
-    if ((rc = launch_blind_rotate(c, d_a, d_b, opsA, uniA, nullptr, 0, c->s_trlwe.as<uint32_t>(), B, -1, st))) return rc;
-    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), d_out, B, st))) return rc;
-    if (mux.empty()) return TFHE_OK;
-    // pass B: y = ANDNY(a, c) on the MUX items; pass C: out = OR(x, y)
-    const int Mx = (int)mux.size();
-    const size_t rows = (size_t)Mx * n1 * sizeof(uint32_t);
-    if ((rc = c->s_idx.reserve(Mx * sizeof(int)))) return rc;
-    if ((rc = c->s_t0.reserve(rows)) || (rc = c->s_t1.reserve(rows)) || (rc = c->s_t2.reserve(rows))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->s_idx.p, mux.data(), Mx * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const int *d_idx = c->s_idx.as<int>();
-    uint32_t *t0 = c->s_t0.as<uint32_t>(), *t1 = c->s_t1.as<uint32_t>(), *t2 = c->s_t2.as<uint32_t>();
-    hipLaunchKernelGGL(k_gather_rows, dim3(Mx), dim3(256), 0, st, d_a, d_idx, t0, n1, Mx);
-    hipLaunchKernelGGL(k_gather_rows, dim3(Mx), dim3(256), 0, st, d_c, d_idx, t1, n1, Mx);
-    if ((rc = launch_blind_rotate(c, t0, t1, nullptr, TFHE_OP_ANDNY, nullptr, 0, c->s_trlwe.as<uint32_t>(), Mx, -1, st))) return rc;
-    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), t2, Mx, st))) return rc;
-    hipLaunchKernelGGL(k_gather_rows, dim3(Mx), dim3(256), 0, st, (const uint32_t *)d_out, d_idx, t0, n1, Mx);
-    if ((rc = launch_blind_rotate(c, t0, t2, nullptr, TFHE_OP_OR, nullptr, 0, c->s_trlwe.as<uint32_t>(), Mx, -1, st))) return rc;
-    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), t1, Mx, st))) return rc;
-    hipLaunchKernelGGL(k_scatter_rows, dim3(Mx), dim3(256), 0, st, (const uint32_t *)t1, d_idx, d_out, n1, Mx);
-    HIP_TRY(hipGetLastError());
     return TFHE_OK;
+}
+
+// Plain / LUT bootstraps of B items in slabs (see slab_items).
+int bootstrap_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item, uint32_t *d_out, int B,
+                     hipStream_t st)
+{
+    int rc;
+    if ((rc = reserve_scratch(c, B, false))) return rc;
+    const size_t n1 = (size_t)c->P.n + 1, trlw = (size_t)2 * c->P.N;
+    const int slab = slab_items(c);
+    for (int base = 0; base < B; base += slab) {
+        const int S = B - base < slab ? B - base : slab;
+        RotateJob j;
+        j.in0 = d_in + base * n1; j.out = c->s_trlwe.as<uint32_t>(); j.B = S;
+        j.tv = d_tv ? d_tv + (tv_per_item ? base * trlw : 0) : nullptr; j.tv_per_item = tv_per_item;
+        if ((rc = launch_blind_rotate(c, j, st)) || (rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), d_out + base * n1, S, nullptr, st)))
+            return rc;
+    }
+    return TFHE_OK;
+}
+
+// Reads and clears the device status word (after the caller has synchronised the stream the work ran on).
+int check_status(tfhe_ctx *c)
+{
+    int st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status.p, sizeof st, hipMemcpyDeviceToHost));
+    if (!st) return TFHE_OK;
+    HIP_TRY(hipMemset(c->status.p, 0, sizeof st));
+    return fail(TFHE_E_INVALID, "an earlier gate batch carried an op code outside TFHE_OP_NAND..TFHE_OP_MUX "
+                                "(or a MUX without a third operand); those items ran as plain bootstraps of their first operand");
 }
 
 } // namespace
@@ -441,6 +525,8 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
         if ((rc = c->twq.reserve(twq.size() * sizeof(cd)))) return rc;
         HIP_TRY(hipMemcpy(c->twq.p, twq.data(), twq.size() * sizeof(cd), hipMemcpyHostToDevice));
     }
+    if ((rc = c->status.reserve(sizeof(int)))) return rc;
+    HIP_TRY(hipMemset(c->status.p, 0, sizeof(int)));
     std::vector<uint32_t> tv(2 * (size_t)P->N, 0u);              // cloudkey.go:74-85
     for (int j = 0; j < P->N; j++) tv[P->N + j] = 0x20000000u;
     if ((rc = c->gate_tv.reserve(tv.size() * sizeof(uint32_t)))) return rc;
@@ -455,7 +541,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     if (!c) return TFHE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
+    for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->status, &c->s_plan, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
                       &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3})
         b->release();
     for (auto &pair : c->ev)
@@ -479,8 +565,19 @@ int tfhe_ctx_sync(tfhe_ctx *c)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return TFHE_OK;
+    if (c->last_dev_stream_set && !stream_capturing(c->last_dev_stream)) HIP_TRY(hipStreamSynchronize(c->last_dev_stream));
+    return check_status(c);
+}
+
+int tfhe_ctx_reserve(tfhe_ctx *c, int max_batch, int with_mux)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (max_batch < 0) return fail(TFHE_E_INVALID, "bad batch size");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    return reserve_scratch(c, max_batch, with_mux != 0);
 }
 
 int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
@@ -488,7 +585,7 @@ int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!bsk) return fail(TFHE_E_INVALID, "null key");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t elems = bsk_elems(c->P), bytes = elems * sizeof(cd);
     DevBuf raw;
     if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bytes))) { raw.release(); return rc; }
@@ -515,7 +612,7 @@ int tfhe_load_bsk_torus(tfhe_ctx *c, const uint32_t *bsk)
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!bsk) return fail(TFHE_E_INVALID, "null key");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t polys = (size_t)c->P.n * 2 * c->P.L * 2, bytes = polys * c->P.N * sizeof(uint32_t);
     DevBuf raw;
     if ((rc = raw.reserve(bytes)) || (rc = c->bsk.reserve(bsk_elems(c->P) * sizeof(cd)))) { raw.release(); return rc; }
@@ -542,7 +639,7 @@ int tfhe_load_ksk(tfhe_ctx *c, const uint32_t *ksk)
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!ksk) return fail(TFHE_E_INVALID, "null key");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const int n1 = c->P.n + 1, base = 1 << c->P.basebit;
     const size_t ref_bytes = ksk_rows_ref(c->P) * n1 * sizeof(uint32_t);
     const size_t rows_p = ksk_rows_packed(c->P) + 1, total = rows_p * c->n1p;    // + the all-zero padding row
@@ -558,15 +655,21 @@ int tfhe_load_ksk(tfhe_ctx *c, const uint32_t *ksk)
     return TFHE_OK;
 }
 
-int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
-                      uint64_t seed)
+int tfhe_keygen_cloud_seeded(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
+                             const uint64_t *seed128)
 {
+    Seed128 seed{};
+    if (seed128) {
+        seed.lo = seed128[0]; seed.hi = seed128[1];
+    } else if (getrandom(&seed, sizeof seed, 0) != (ssize_t)sizeof seed) {
+        return fail(TFHE_E_INVALID, "getrandom failed: no OS entropy for the key-generation seed");
+    }
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!s0 || !s1) return fail(TFHE_E_INVALID, "null secret key");
     if (!(alpha_lv0 >= 0.0) || !(alpha_lv1 >= 0.0) || alpha_lv0 >= 0.25 || alpha_lv1 >= 0.25)
         return fail(TFHE_E_INVALID, "noise parameters out of range");
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const tfhe_params &P = c->P;
     for (int i = 0; i < P.n; i++) if (s0[i] > 1) return fail(TFHE_E_INVALID, "level-0 key is not binary at %d", i);
     for (int i = 0; i < P.N; i++) if (s1[i] > 1) return fail(TFHE_E_INVALID, "level-1 key is not binary at %d", i);
@@ -603,7 +706,7 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
                            d_spec.as<cd>(), d_s0.as<uint32_t>(), alpha_lv1, seed);
     }
     hipLaunchKernelGGL(k_keygen_ksk, dim3((unsigned)rows_p), dim3(64), 0, st, c->ksk.as<uint32_t>(), d_s0.as<uint32_t>(),
-                       d_s1.as<uint32_t>(), P.n, c->n1p, P.t, P.basebit, rows_p, alpha_lv0, seed ^ 0x9E3779B97F4A7C15ull);
+                       d_s1.as<uint32_t>(), P.n, c->n1p, P.t, P.basebit, rows_p, alpha_lv0, Seed128{seed.lo ^ 0x9E3779B97F4A7C15ull, seed.hi});
     HIP_TRY(hipGetLastError());
     if ((rc = make_quad_key(c, st))) { d_s0.release(); d_s1.release(); d_spec.release(); return rc; }
     HIP_TRY(hipStreamSynchronize(st));
@@ -612,54 +715,59 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
     return TFHE_OK;
 }
 
+int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
+                      uint64_t seed)
+{
+    const uint64_t s[2] = {seed, 0};
+    return tfhe_keygen_cloud_seeded(c, s0, s1, alpha_lv0, alpha_lv1, s);
+}
+
+// _dev entry points: reserve + enqueue under the context mutex (the grow-only buffers, the event lists and the
+// last-stream note are host state), never synchronise, never read device memory.
+#define DEV_PROLOGUE()                                              \
+    int rc = check_ctx(c);                                          \
+    if (rc) return rc;                                              \
+    std::lock_guard<std::recursive_mutex> lk(c->mu);                \
+    hipStream_t st = pick(c, stream);                               \
+    c->last_dev_stream = st; c->last_dev_stream_set = true
+
 int tfhe_blind_rotate_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,
                                 uint32_t *d_out, int B, int nsteps, void *stream)
 {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+    DEV_PROLOGUE();
     if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
-    return launch_blind_rotate(c, d_in, nullptr, nullptr, -1, d_tv, tv_per_item, d_out, B, nsteps, pick(c, stream));
+    RotateJob j;
+    j.in0 = d_in; j.tv = d_tv; j.tv_per_item = tv_per_item; j.out = d_out; j.B = B; j.nsteps = nsteps;
+    return launch_blind_rotate(c, j, st);
 }
 
 int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *c, const uint32_t *d_in, uint32_t *d_out, int B, void *stream)
 {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+    DEV_PROLOGUE();
     if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
-    return launch_keyswitch(c, d_in, d_out, B, pick(c, stream));
+    return launch_keyswitch(c, d_in, d_out, B, nullptr, st);
 }
 
 int tfhe_bootstrap_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,
                              uint32_t *d_out, int B, void *stream)
 {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+    DEV_PROLOGUE();
     if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
-    if ((rc = c->s_trlwe.reserve((size_t)B * 2 * c->P.N * sizeof(uint32_t)))) return rc;
-    hipStream_t st = pick(c, stream);
-    if ((rc = launch_blind_rotate(c, d_in, nullptr, nullptr, -1, d_tv, tv_per_item, c->s_trlwe.as<uint32_t>(), B, -1, st))) return rc;
-    return launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), d_out, B, st);
+    return bootstrap_device(c, d_in, d_tv, tv_per_item, d_out, B, st);
 }
 
 int tfhe_gate_batch_dev(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a, const uint32_t *d_b,
                         const uint32_t *d_c, uint32_t *d_out, int B, void *stream)
 {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+    DEV_PROLOGUE();
     if (B < 0 || (B > 0 && (!d_a || !d_b || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
-    hipStream_t st = pick(c, stream);
-    std::vector<uint8_t> h_ops;
-    if (d_ops) {            // the MUX split needs the op codes on the host
-        h_ops.resize(B);
-        HIP_TRY(hipMemcpyAsync(h_ops.data(), d_ops, B, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    return gate_batch_device(c, d_ops, d_ops ? h_ops.data() : nullptr, op_uniform, d_a, d_b, d_c, d_out, B, st);
+    return gate_batch_device(c, d_ops, op_uniform, d_a, d_b, d_c, d_out, B, st);
 }
+#undef DEV_PROLOGUE
 
 // ---- host-pointer variants: stage, run, copy back, synchronise -----------------------
 
@@ -670,14 +778,18 @@ int tfhe_blind_rotate_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv,
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (B == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
     const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
     if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_trlwe.reserve(trl)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
     if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
-    if ((rc = launch_blind_rotate(c, c->s_in0.as<uint32_t>(), nullptr, nullptr, -1, tv ? c->s_tv.as<uint32_t>() : nullptr,
-                                  tv_per_item, c->s_trlwe.as<uint32_t>(), B, nsteps, c->stream))) return rc;
+    {
+        RotateJob j;
+        j.in0 = c->s_in0.as<uint32_t>(); j.tv = tv ? c->s_tv.as<uint32_t>() : nullptr; j.tv_per_item = tv_per_item;
+        j.out = c->s_trlwe.as<uint32_t>(); j.B = B; j.nsteps = nsteps;
+        if ((rc = launch_blind_rotate(c, j, c->stream))) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(out, c->s_trlwe.p, trl, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;
@@ -689,11 +801,11 @@ int tfhe_extract_keyswitch_batch(tfhe_ctx *c, const uint32_t *in, uint32_t *out,
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (B == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t outb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
     if ((rc = c->s_out.reserve(outb)) || (rc = c->s_trlwe.reserve(trl))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
-    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), c->s_out.as<uint32_t>(), B, c->stream))) return rc;
+    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), c->s_out.as<uint32_t>(), B, nullptr, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->s_out.p, outb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;
@@ -705,14 +817,14 @@ int tfhe_bootstrap_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, in
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (B == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
     const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
     if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_out.reserve(inb)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
     if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
-    if ((rc = tfhe_bootstrap_batch_dev(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
-                                       c->s_out.as<uint32_t>(), B, (void *)c->stream))) return rc;
+    if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
+                               c->s_out.as<uint32_t>(), B, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;
@@ -726,7 +838,13 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
     if (B < 0 || (B > 0 && (!a || !b || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    if (ops) {              // the op codes are on the host here: refuse bad ones before any work is issued
+        for (int i = 0; i < B; i++) {
+            if (ops[i] > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d at item %d", ops[i], i);
+            if (ops[i] == TFHE_OP_MUX && !cc) return fail(TFHE_E_INVALID, "MUX needs the third operand");
+        }
+    }
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
     if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_in1.reserve(rows)) || (rc = c->s_out.reserve(rows))) return rc;
     if (cc && (rc = c->s_in2.reserve(rows))) return rc;
@@ -735,7 +853,7 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
     HIP_TRY(hipMemcpyAsync(c->s_in1.p, b, rows, hipMemcpyHostToDevice, c->stream));
     if (cc) HIP_TRY(hipMemcpyAsync(c->s_in2.p, cc, rows, hipMemcpyHostToDevice, c->stream));
     if (ops) HIP_TRY(hipMemcpyAsync(c->s_ops.p, ops, B, hipMemcpyHostToDevice, c->stream));
-    if ((rc = gate_batch_device(c, ops ? c->s_ops.as<uint8_t>() : nullptr, ops, op_uniform, c->s_in0.as<uint32_t>(),
+    if ((rc = gate_batch_device(c, ops ? c->s_ops.as<uint8_t>() : nullptr, op_uniform, c->s_in0.as<uint32_t>(),
                                 c->s_in1.as<uint32_t>(), cc ? c->s_in2.as<uint32_t>() : nullptr,
                                 c->s_out.as<uint32_t>(), B, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->s_out.p, rows, hipMemcpyDeviceToHost, c->stream));
@@ -751,7 +869,7 @@ int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, 
     if (!c->have_bsk) return fail(TFHE_E_NOKEY, "bootstrapping key not loaded");
     if (key_index < 0 || key_index >= c->P.n) return fail(TFHE_E_INVALID, "key index %d out of range", key_index);
     if (B == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t trl = (size_t)B * 2 * c->P.N * 4;
     if ((rc = c->s_trlwe.reserve(trl)) || (rc = c->s_t0.reserve(trl))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
@@ -769,7 +887,7 @@ int tfhe_to_fourier_batch(tfhe_ctx *c, const uint32_t *polys, double *spectra, i
     if (rc) return rc;
     if (P < 0 || (P > 0 && (!polys || !spectra))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (P == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
     if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t0.p, polys, pb, hipMemcpyHostToDevice, c->stream));
@@ -794,7 +912,7 @@ int tfhe_to_poly_batch(tfhe_ctx *c, const double *spectra, uint32_t *polys, int 
     if (rc) return rc;
     if (P < 0 || (P > 0 && (!polys || !spectra))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (P == 0) return TFHE_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
     if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t1.p, spectra, sb, hipMemcpyHostToDevice, c->stream));

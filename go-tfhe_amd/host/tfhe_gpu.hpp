@@ -93,8 +93,14 @@ class CloudKey {
     CloudKey(const params::Params &p, const double *bsk_fourier, const uint32_t *ksk, int device = 0) : P(p)
     {
         check(tfhe_ctx_create(&P, device, &ctx_));
-        if (bsk_fourier) check(tfhe_load_bsk_fourier(ctx_, bsk_fourier));
-        if (ksk) check(tfhe_load_ksk(ctx_, ksk));
+        try {
+            if (bsk_fourier) check(tfhe_load_bsk_fourier(ctx_, bsk_fourier));
+            if (ksk) check(tfhe_load_ksk(ctx_, ksk));
+        } catch (...) {          // a throwing constructor runs no destructor: release the context here
+            tfhe_ctx_destroy(ctx_);
+            ctx_ = nullptr;
+            throw;
+        }
     }
     // coefficient-domain bootstrapping key (trgsw.TRGSWLv1), [n][2L][2][N] uint32
     static std::unique_ptr<CloudKey> FromTorus(const params::Params &p, const uint32_t *bsk_torus, const uint32_t *ksk, int device = 0)
@@ -103,14 +109,16 @@ class CloudKey {
         check(tfhe_load_bsk_torus(ck->ctx_, bsk_torus));
         return ck;
     }
-    // cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31), generated on the GPU
+    // cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31), generated on the GPU.  seed128 = nullptr (the default)
+    // draws 128 bits from the OS entropy source, like the reference's auto-seeded generator; a fixed seed is for
+    // tests only: the seed is secret key material (include/tfhe_hip.h).
     static std::unique_ptr<CloudKey> NewCloudKey(const params::Params &p, const std::vector<uint32_t> &keyLv0,
                                                  const std::vector<uint32_t> &keyLv1, double alphaLv0, double alphaLv1,
-                                                 uint64_t seed, int device = 0)
+                                                 const uint64_t *seed128 = nullptr, int device = 0)
     {
         auto ck = std::make_unique<CloudKey>(p, nullptr, nullptr, device);
         if ((int)keyLv0.size() != p.n || (int)keyLv1.size() != p.N) throw Panic(TFHE_E_INVALID, "secret key has the wrong length");
-        check(tfhe_keygen_cloud(ck->ctx_, keyLv0.data(), keyLv1.data(), alphaLv0, alphaLv1, seed));
+        check(tfhe_keygen_cloud_seeded(ck->ctx_, keyLv0.data(), keyLv1.data(), alphaLv0, alphaLv1, seed128));
         return ck;
     }
     ~CloudKey() { if (ctx_) tfhe_ctx_destroy(ctx_); }

@@ -16,12 +16,17 @@
  *   - keys are copied at load time and are immutable afterwards.
  *   - outputs are caller-owned (the *Assign style of the reference).
  *   - "_dev" variants take DEVICE pointers and a hipStream_t (as void*; NULL = HIP's
- *     default stream, as for any hipStream_t) and only enqueue work on that stream, ordered
- *     with the caller's other work there; the others take HOST pointers, run on the
- *     context's private stream and return after the result is in the output buffer.
- *     "_dev" calls of one context share its intermediate TRLWE buffer: enqueue them on ONE
- *     stream at a time (stream order keeps them correct); for independent streams use one
- *     context per stream.  Host-pointer calls of one context are serialised by a mutex.
+ *     default stream, as for any hipStream_t) and ONLY ENQUEUE work on that stream, ordered
+ *     with the caller's other work there: no device memory is read back, nothing is
+ *     synchronised, so a sequence of them can be captured into a hipGraph (size the context's
+ *     intermediate buffers first: tfhe_ctx_reserve, or one un-captured call of the same batch
+ *     size -- hipMalloc is not allowed during capture).  The others take HOST pointers, run on
+ *     the context's private stream and return after the result is in the output buffer.
+ *     All calls of one context are serialised by a mutex while they reserve and enqueue, but
+ *     the "_dev" calls of one context share its intermediate device buffers: their work must be
+ *     ordered on ONE stream at a time (stream order keeps it correct), and "_dev" work must
+ *     not be in flight while a host-pointer call of the same context runs.  For independent
+ *     streams use one context per stream.
  *   - all ciphertext words are uint32 torus values (params.Torus, params.go:27);
  *     an LWE sample is n+1 words with the body LAST (tlwe.go:11-33); a TRLWE sample is
  *     [2][N] words, A then B (trlwe.go:13-16).
@@ -77,7 +82,16 @@ int tfhe_device_count(int *count);
 int tfhe_ctx_create(const tfhe_params *params, int device_id, tfhe_ctx **out);
 int tfhe_ctx_destroy(tfhe_ctx *ctx);
 int tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
+/* Waits for the context's private stream and for the stream of its most recent "_dev" call, then reports
+ * (TFHE_E_INVALID) and clears anything the kernels recorded since the last call: an op code outside
+ * TFHE_OP_NAND..TFHE_OP_MUX, or a MUX item without a third operand, in a tfhe_gate_batch_dev whose op codes the
+ * host never sees.  Such items ran as plain bootstraps of their first operand. */
 int tfhe_ctx_sync(tfhe_ctx *ctx);
+/* Sizes the context's intermediate device buffers for "_dev" batches of up to max_batch items (with_mux: for gate
+ * batches that may contain MUX items) so that later calls allocate nothing -- required before capturing "_dev"
+ * calls into a hipGraph.  Work is issued in slabs of 16 co-resident launches (16,384 bootstraps at N = 1024), so the
+ * buffers stop growing there: 134 MB, 268 MB with MUX. */
+int tfhe_ctx_reserve(tfhe_ctx *ctx, int max_batch, int with_mux);
 
 /* CloudKey.BootstrappingKey (cloudkey.go:16-21, []*trgsw.TRGSWLv1FFT, trgsw.go:60-68),
  * flattened by the shim to [n][2L][2][N] float64: row r < L multiplies the digits of A,
@@ -98,8 +112,13 @@ int tfhe_load_ksk(tfhe_ctx *ctx, const uint32_t *ksk);
  * straight into the engine's device layouts -- no host-side key, no upload.
  *   s0 [n], s1 [N]: the binary secret keys (key.SecretKey.KeyLv0 / KeyLv1, key.go:10-13)
  *   alpha_lv0 = params.KSKAlpha(), alpha_lv1 = params.BSKAlpha()   (params.go:629-636)
- *   seed: the reference is unseeded (math/rand auto-seed); here the same (seed, key) pair always
- *         gives the same cloud key (counter-based Philox streams). */
+ *   seed128: two 64-bit words, or NULL = 128 bits from the OS entropy source (getrandom), which is what the
+ *         reference's auto-seeded math/rand corresponds to.  The same (seed, secret key) pair always gives the
+ *         same cloud key (counter-based Philox streams) -- so the seed is SECRET key material: every mask and
+ *         noise sample of the published cloud key is a function of it.  Pass fixed seeds in tests only. */
+int tfhe_keygen_cloud_seeded(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *s1, double alpha_lv0,
+                             double alpha_lv1, const uint64_t *seed128);
+/* The same with a 64-bit test seed (= seed128 {seed, 0}). */
 int tfhe_keygen_cloud(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *s1, double alpha_lv0,
                       double alpha_lv1, uint64_t seed);
 
@@ -141,8 +160,10 @@ int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, 
  *   gates.go:107-114), may be NULL otherwise.
  * Batch XNOR follows the tested scalar gates.XNOR (+1/4, gates.go:52-58), not
  * BatchXNOR's -1/4 (gates.go:293), which computes XOR.
- * The _dev variant is enqueue-only for a uniform op; with per-item op codes it copies them
- * back and synchronises the stream once (the MUX items have to be split out on the host). */
+ * MUX items are found and compacted on the device (no op code is ever copied back): one blind-rotate request
+ * covers every item's own gate (a MUX item's AND(a,b)) plus ANDNY(a,c) of the MUX items, a second one their OR.
+ * The host-pointer variant validates the op codes before issuing anything; the _dev variant cannot (see
+ * tfhe_ctx_sync). */
 int tfhe_gate_batch(tfhe_ctx *ctx, const uint8_t *ops, int op_uniform, const uint32_t *a,
                     const uint32_t *b, const uint32_t *c, uint32_t *out, int B);
 int tfhe_gate_batch_dev(tfhe_ctx *ctx, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a,

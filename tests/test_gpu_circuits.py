@@ -17,6 +17,55 @@ def test_adder_structure(pkg):
     levels, n_wires, sums, cout = ripple_carry_adder(8)
     assert len(levels) == 15 + 0 or len(levels) >= 15       # 1 + 2*7 dependency levels
     assert count_gates(levels) == 2 * 8 + 3 * 7               # 37: the folded carry-in saves 3 of the 40
+    ref_levels, nw, sums, cout = ripple_carry_adder(8, fold_carry_in=False)
+    assert count_gates(ref_levels) == 40 and len(ref_levels) == 17      # README.md:78-106 as written
+    assert [len(l) for l in ref_levels] == [16] + [2, 1] * 8
+
+
+def test_adder_reference_form_40_gates_x256_128bit(oracle, keys128, ck128, pkg):
+    # BASELINE config 3 exactly as the reference writes it: 8 FullAdders chained from carry := Constant(false)
+    # (README.md:78-106; the constant is the trivial sample with body 1 - 1/8 = 0xE0000001, gates.go:61-69), 256
+    # circuits at once.  Sums decrypt to (a+b) mod 256; one circuit is re-done gate by gate on the oracle and
+    # every wire is the identical ciphertext; a graph replay of the captured level loop reproduces the run.
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor
+    k = keys128
+    C, bits = 256, 8
+    levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+    rs = np.random.RandomState(43)
+    av, bv = rs.randint(0, 256, C), rs.randint(0, 256, C)
+    n1 = k.p.n + 1
+    wires = np.zeros((n_wires, C, n1), np.uint32)
+    for i in range(bits):
+        wires[i] = k.enc((av >> i) & 1)
+        wires[bits + i] = k.enc((bv >> i) & 1)
+    cw = adder_constant_wire(bits)
+    const_false = pkg.gates.Constant(False, k.p)
+    assert const_false[k.p.n] == 0xE0000001 and not const_false[:k.p.n].any()
+    wires[cw] = const_false
+    wt = torch.from_numpy(wires.view(np.int32)).cuda()
+    ex = CircuitExecutor(ck128.ctx, levels, n_wires)
+    ex.run(wt)
+    torch.cuda.synchronize()
+    res = wt.cpu().numpy().view(np.uint32)
+    got = np.zeros(C, np.int64)
+    for i, w in enumerate(sums):
+        got |= k.dec(res[w]).astype(np.int64) << i
+    assert np.array_equal(got, (av + bv) % 256)
+    assert np.array_equal(k.dec(res[cout]).astype(np.int64), (av + bv) >> 8)
+    c0 = 101
+    ow = {w: wires[w, c0] for w in list(range(2 * bits)) + [cw]}
+    for lvl in levels:
+        for (op, x, y, z, out) in lvl:
+            ow[out] = oracle.gate(k.p, k.bsk, k.ksk, op, np.ascontiguousarray(ow[x]), np.ascontiguousarray(ow[y]))
+    for w, v in ow.items():
+        assert np.array_equal(res[w, c0], v), w
+    # the same level loop captured into a HIP graph and replayed on fresh inputs
+    wt2 = torch.from_numpy(wires.view(np.int32)).cuda()
+    graph = ex.capture(wt2)
+    wt2.copy_(torch.from_numpy(wires.view(np.int32)))       # capture ran the circuit once: restore the inputs
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(wt2, wt)
 
 
 def test_adder_8bit_x256_128bit(oracle, keys128, ck128, pkg):
@@ -79,10 +128,50 @@ def test_mixed_stream_4096_128bit(oracle, keys128, ck128, pkg):
     ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops[sample], np.ascontiguousarray(a[sample]),
                                np.ascontiguousarray(b[sample]), np.ascontiguousarray(c[sample]))
     assert np.array_equal(out[sample], ref)
+    # the device-pointer entry point never sees the op codes on the host (the MUX items are compacted on the GPU):
+    # same ciphertexts, and a second stream with a different MUX density through the same context
+    ad, bd, cd_ = (torch.from_numpy(np.ascontiguousarray(v).view(np.int32)).cuda() for v in (a, b, c))
+    od = torch.empty_like(ad)
+    ck128.ctx.gate_batch_dev(torch.from_numpy(ops).cuda(), ad, bd, cd_, od)
+    torch.cuda.synchronize()
+    assert np.array_equal(od.cpu().numpy().view(np.uint32), out)
+    ck128.ctx.sync()                                         # nothing was rejected
+    for ops2 in (np.full(300, pkg.OPS["MUX"], np.uint8), np.array([pkg.OPS["XOR"]] * 299 + [pkg.OPS["MUX"]], np.uint8)):
+        o2 = torch.empty_like(ad[:300])
+        ck128.ctx.gate_batch_dev(torch.from_numpy(ops2).cuda(), ad[:300].contiguous(), bd[:300].contiguous(), cd_[:300].contiguous(), o2)
+        torch.cuda.synchronize()
+        want2 = ck128.ctx.gate_batch(ops2, a[:300], b[:300], c[:300])
+        assert np.array_equal(o2.cpu().numpy().view(np.uint32), want2)
+    om = torch.empty_like(ad[:64])
+    ck128.ctx.gate_batch_dev("MUX", ad[:64].contiguous(), bd[:64].contiguous(), cd_[:64].contiguous(), om)
+    torch.cuda.synchronize()
+    assert np.array_equal(om.cpu().numpy().view(np.uint32), ck128.ctx.gate_batch("MUX", a[:64], b[:64], c[:64]))
+
+
+def test_dev_path_reports_bad_op_codes_at_sync(ck128, keys128, pkg):
+    # tfhe_gate_batch_dev never copies the op codes back, so it cannot refuse them up front: the kernels record
+    # the problem and tfhe_ctx_sync reports it once.  The host-pointer call still validates before issuing work.
+    k = keys128
+    rs = np.random.RandomState(5)
+    a = torch.from_numpy(rand_u32(rs, (8, k.p.n + 1)).view(np.int32)).cuda()
+    out = torch.empty_like(a)
+    bad = torch.tensor([0, 1, 2, 3, 4, 11, 6, 7], dtype=torch.uint8).cuda()
+    ck128.ctx.gate_batch_dev(bad, a, a, a, out)
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.TfheError):
+        ck128.ctx.sync()
+    ck128.ctx.sync()                                         # reported once, then cleared
+    muxes = torch.full((8,), pkg.OPS["MUX"], dtype=torch.uint8).cuda()
+    ck128.ctx.gate_batch_dev(muxes, a, a, None, out)         # MUX without a third operand
+    torch.cuda.synchronize()
+    with pytest.raises(pkg.TfheError):
+        ck128.ctx.sync()
+    with pytest.raises(pkg.TfheError):
+        ck128.ctx.gate_batch(np.array([11], np.uint8), a[:1].cpu().numpy().view(np.uint32), a[:1].cpu().numpy().view(np.uint32))
 
 
 def test_mixed_stream_per_gpu_share_131072(oracle, keys128, ck128, pkg):
-    # BASELINE config 4 (1M mixed gates over 8 GPUs) at one GPU's full share, 2^20 / 8 gates, checked through
+    # BASELINE config 5 (SURVEY 8d numbering; BASELINE.json configs[4]: 1M mixed gates over 8 GPUs) at one GPU's full share, 2^20 / 8 gates, checked through
     # size-independent properties: every output decrypts to its truth-table value, a second run is
     # bit-identical (chunked launches and the three MUX passes are deterministic), a sample equals the oracle.
     k = keys128
