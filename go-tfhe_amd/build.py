@@ -1,6 +1,7 @@
 """Build the gfx950 shared library (hipcc cross-compiles without a GPU)."""
 import os
 import subprocess
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
@@ -23,9 +24,9 @@ def _stale():
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into lib/libtfhe_hip.so (no-op when up to date)."""
     if not force and not _stale():
-        print(f"[build] {os.path.relpath(LIB_PATH)}: up to date with csrc/ (reused)")
+        print(f"[build] {os.path.relpath(LIB_PATH)}: up to date with csrc/ (reused)", file=sys.stderr)
         return LIB_PATH
-    print(f"[build] compiling {', '.join(x for x, _ in SOURCES)} for gfx950 -> {os.path.relpath(LIB_PATH)}", flush=True)
+    print(f"[build] compiling {', '.join(x for x, _ in SOURCES)} for gfx950 -> {os.path.relpath(LIB_PATH)}", file=sys.stderr, flush=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     procs = []

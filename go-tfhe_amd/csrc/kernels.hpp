@@ -102,7 +102,10 @@ __device__ __forceinline__ bool gate_item_live(const BlindRotateArgs &A, int v)
 
 // Prologue shared by every blind-rotate kernel: gate linear preparation (gates_helper.go:10-63) and mod-switch of
 // the n+1 words of item v (evaluator.go:116,122) by threads tid, tid + nthreads, ... into abar[0..n) and bt.
-__device__ __forceinline__ void gate_prep_modswitch(const BlindRotateArgs &A, int v, int tid, int nthreads, int N,
+// Returns whether the item's op code is one the launch cannot run; the caller reports it with
+// report_bad_op() AFTER its CMUX loop: a global atomic ahead of the loop makes every later load "possibly
+// clobbered", and the wave-uniform twiddle loads then stop being scalar loads (measured: 6.3 -> 7.7 ms).
+__device__ __forceinline__ bool gate_prep_modswitch(const BlindRotateArgs &A, int v, int tid, int nthreads, int N,
                                                     uint16_t *abar, int *bt)
 {
     const int n = A.n;
@@ -120,9 +123,9 @@ __device__ __forceinline__ void gate_prep_modswitch(const BlindRotateArgs &A, in
             op = A.list_op;
         }
     }
-    // a two-operand launch only knows the ten binary gates (MUX exists as the three passes of the list form):
+    // a two-operand launch only knows the ten binary gates (MUX exists as the passes of the list form):
     // anything else is recorded for tfhe_ctx_sync and runs as a plain bootstrap of the first operand
-    if (p1 && (op < 0 || op > 9) && tid == 0 && A.status) atomicOr(A.status, kStatusBadOp);
+    const bool bad = p1 && (op < 0 || op > 9);
     const GateCoef g = gate_coef(p1 ? op : -1);
     const uint32_t *x0 = A.in0 + r0 * (n + 1);
     const uint32_t *x1 = p1 ? p1 + r1 * (n + 1) : x0;
@@ -137,6 +140,12 @@ __device__ __forceinline__ void gate_prep_modswitch(const BlindRotateArgs &A, in
             abar[x] = (uint16_t)((uint32_t)(w + rnd) >> sh);               // wraps (evaluator.go:122)
         }
     }
+    return bad;
+}
+
+__device__ __forceinline__ void report_bad_op(const BlindRotateArgs &A, bool bad, int tid)
+{
+    if (bad && tid == 0 && A.status) atomicOr(A.status, kStatusBadOp);
 }
 
 constexpr int kMaxLweDim = 1280;      // Uint7/8 use n = 1160 (params.go:444-510)
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
     const int n = A.n;
 
     // ---- gate linear prep + mod-switch (gates_helper.go:10-63, evaluator.go:116,122)
-    gate_prep_modswitch(A, item, tid, 128, N, abarL, &btL);
+    const bool bad_op = gate_prep_modswitch(A, item, tid, 128, N, abarL, &btL);
     LaneTwiddles tw;
     load_lane_twiddles(tw, A.tw, lane);
     __syncthreads();
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) out[64 * q + lane] = accL[p][64 * q + lane];
+    report_bad_op(A, bad_op, tid);
 }
 
 // ExternalProductAssign of in[b] with bsk[key_index] (test seam).

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
     const bool live = ITEMS == 1 || (blockIdx.x * ITEMS + grp < A.batch && gate_item_live(A, item));
     if (!live) item = wg_first;                     // the idle group recomputes the first item, stores nothing
     const int n = A.n;
-    gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
+    const bool bad_op = gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
     LaneTwiddles tw;
     const cd *table = A.tw + (size_t)h * kTwCount1024;
     load_lane_twiddles(tw, table, lane);
@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
         const int j = (q < 8 ? 64 * q + lane : 64 * (q - 8) + lane + 1024) + 512 * h;
         out[j] = accL[p][j];
     }
+    report_bad_op(A, bad_op, tid);
 }
 
 template <int BGBIT>

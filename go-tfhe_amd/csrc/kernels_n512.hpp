@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate_512(BlindRotateArgs A)
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
     const int item = A.first + blockIdx.x;
     if (!gate_item_live(A, item)) return;           // list entries past the device-side count (kernels.hpp)
-    gate_prep_modswitch(A, item, lane, 64, N, abarL, &btL);
+    const bool bad_op = gate_prep_modswitch(A, item, lane, 64, N, abarL, &btL);
     LaneTwiddles512 tw;
     load_lane_twiddles_512(tw, A.tw, hl);
     __syncthreads();
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate_512(BlindRotateArgs A)
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)h * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) out[32 * q + hl] = acc[32 * q + hl];
+    report_bad_op(A, bad_op, lane);
 }
 
 // ExternalProductAssign of in[b] with bsk[key_index] (test seam).

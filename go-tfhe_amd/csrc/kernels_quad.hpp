@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
     const int n = A.n;
 
     // ---- gate linear prep + mod-switch (gates_helper.go:10-63, evaluator.go:116,122)
-    gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
+    const bool bad_op = gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
     const cd *T = A.twq + (size_t)h * kTwQuadHalf;
     QuadTwiddles tw;
     load_quad_twiddles(tw, T, lane);
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
         const int j = 64 * (k & 3) + lane + 256 * h + 512 * (k >> 2);
         out[j] = acc[j];
     }
+    report_bad_op(A, bad_op, tid);
 }
 
 } // namespace tfhe

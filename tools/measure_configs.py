@@ -24,21 +24,22 @@ def timed(fn, reps):
 p = pkg.params.Security128Bit
 ck = pkg.CloudKey(p, bsk_torus=rnd((p.n, 2 * p.L, 2, p.N)), ksk=rnd((p.ksk_rows, p.n + 1)))
 n1 = p.n + 1
-# config 3: 8-bit ripple-carry adder x 256 circuits
-levels, nw, sums, cout = ripple_carry_adder(8)
-wires = torch.from_numpy(rnd((nw, 256, n1)).view(np.int32)).cuda()
-ex = CircuitExecutor(ck.ctx, levels, nw)
-dt = timed(lambda: ex.run(wires), 5)
-G = count_gates(levels) * 256
-out["config3_adder8_x256"] = {"gates": G, "levels": len(levels), "seconds": dt, "gates_per_s": G / dt,
-                              "adds_per_s": 256 / dt, "schedule": "ASAP levels (4096-gate first level)"}
+# config 3: 8-bit ripple-carry adder x 256 circuits.  "reference" = the 40-gate circuit exactly as README.md:78-106
+# writes it (8 FullAdders from Constant(false): the contractual workload); "folded" = 37 gates (carry-in folded away).
 from go_tfhe_amd.circuits import balance_levels
-bal = balance_levels(levels, 1024 // 256)
-exb = CircuitExecutor(ck.ctx, bal, nw)
-dt = timed(lambda: exb.run(wires), 5)
-out["config3_adder8_x256_balanced"] = {"gates": G, "levels": len(bal), "widths": [len(l) for l in bal], "seconds": dt,
-                                       "gates_per_s": G / dt, "adds_per_s": 256 / dt,
-                                       "schedule": "balance_levels(width = 1024 / circuits)"}
+for tag, fold in (("reference40", False), ("folded37", True)):
+    levels, nw, sums, cout = ripple_carry_adder(8, fold_carry_in=fold)
+    wires = torch.from_numpy(rnd((nw, 256, n1)).view(np.int32)).cuda()
+    G = count_gates(levels) * 256
+    for sched, lv in (("asap", levels), ("balanced", balance_levels(levels, 1024 // 256))):
+        ex = CircuitExecutor(ck.ctx, lv, nw)
+        dt = timed(lambda: ex.run(wires), 5)
+        graph = ex.capture(wires)
+        dtg = timed(lambda: graph.replay(), 5)
+        out[f"config3_adder8_x256_{tag}_{sched}"] = {
+            "gates": G, "levels": len(lv), "widths": [len(l) for l in lv], "seconds": dt, "gates_per_s": G / dt,
+            "adds_per_s": 256 / dt, "graph_replay_seconds": dtg, "graph_gates_per_s": G / dtg}
+        del graph
 # config 5 (one-GPU slice): mixed AND/OR/XOR/MUX stream, 65536 gates
 B = 65536
 ops = torch.from_numpy(np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, B)]).cuda()
