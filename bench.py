@@ -5,12 +5,24 @@ One "step" = one pass of the hot path over BASELINE.json configs[1]: a batch of 
 independent NAND gates at the 128-bit parameter set (n=700, N=1024) per GPU -- fused gate
 prep + blind rotate (700 CMUX steps) + sample extract + key switch -- with keys and inputs
 already resident in HBM.  Multi-GPU is weak scaling: every rank owns a full cloud-key replica
-and its own 1024-gate shard, no collective on the data path.
+(generated once, broadcast from rank 0 as a device-layout blob over RCCL) and its own 1024-gate
+shard, no collective on the data path.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_blind_rotate):
-algorithmic bytes per launch / mean launch duration measured with HIP events on the launch
-stream.  `cpu_baseline` (N=1, rank 0) times the C oracle (a port of the Go reference, which
-cannot run here: no Go toolchain) on the host cores over a bounded sample of the same gates.
+The key is a REAL seeded cloud key and the inputs are real encryptions of random bits, so the
+output of the last timed step is checked after the timed region ("verified"): every one of the 1024
+outputs decrypts to NAND of its inputs and three sampled outputs are bit-identical to the CPU oracle.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_blind_rotate): it is
+bound by fp64 vector issue, not by HBM -- all 1024 bootstraps of a launch walk the same key, which
+each XCD's L2 fetches once -- so `frac` is achieved fp64 TFLOP/s over the 78.6 TFLOP/s vector peak;
+the HBM streaming figure BASELINE.json's metric asks for is reported beside it (`hbm_streaming`).
+`cpu_baseline` (N=1, rank 0) times the C oracle (a port of the Go reference, which cannot run here:
+no Go toolchain) on the host cores over a bounded sample of the same gates.
+
+--mode sharded times the path the north star names for multi-GPU work that starts on ONE rank:
+root holds the batch, scatter -> local gate batch -> gather inside the timed region
+(--workload mixed: BASELINE config 5, AND/OR/XOR/MUX stream; --workload adder: config 3, the 40-gate
+ripple-carry adder sharded by circuit); it prints scatter / compute / gather milliseconds separately.
 """
 import argparse
 import json
@@ -28,6 +40,7 @@ import __graft_entry__ as graft  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
 BATCH = 1024
+KEY_SEED = 0x7F4E0002
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/prof_pmc.sh (rocprofv3 --pmc passes)
 
 
@@ -80,28 +93,41 @@ def effective_cores():
     return n
 
 
-def cpu_baseline(p128, a, b, bsk_torus, ksk, budget_s=12.0):
+class SeededKey:
+    """Seeded secret + cloud key and encrypt/decrypt from the oracle's harness (tests/oracle_lib.py): input
+    generator and checker only -- nothing of it runs inside a timed region."""
+
+    def __init__(self, seed=KEY_SEED):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import Oracle
+        self.o = Oracle()
+        self.p = self.o.params("128")
+        self.rng = self.o.rng(seed)
+        self.s0, self.s1 = self.o.keygen_secret(self.p, self.rng)
+        self.bsk_torus, self.bsk = self.o.keygen_bsk(self.p, self.rng, self.s0, self.s1, torus=True, fourier=True)
+        self.ksk = self.o.keygen_ksk(self.p, self.rng, self.s0, self.s1)
+
+    def enc(self, bits, seed):
+        return self.o.encrypt_bools(self.p, self.o.rng(seed), np.asarray(bits), self.s0)
+
+    def dec(self, cts):
+        return self.o.decrypt_bools(self.p, self.s0, cts)
+
+
+def cpu_baseline(key, a, b, budget_s=12.0):
     """Oracle (port of the reference) on the host cores: all threads, one bootstrap per thread
     (mirrors trgsw.BatchBlindRotate's goroutine per input, trgsw.go:234-252)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import Oracle
-    o = Oracle()
-    p = o.params("128")
-    bsk_f = np.empty(bsk_torus.shape, np.float64)
-    flat_t = bsk_torus.reshape(-1, p.N)
-    flat_f = bsk_f.reshape(-1, p.N)
-    for i in range(flat_t.shape[0]):
-        flat_f[i] = o.to_fourier(flat_t[i])
+    o, p = key.o, key.p
     cores = effective_cores()
     # single-thread latency on 2 gates (comparable to BenchmarkBootstrapNAND, gates_test.go:505-518)
     t0 = time.perf_counter()
-    o.gate_batch(p, bsk_f, ksk, "NAND", a[:2], b[:2], nthreads=1)
+    o.gate_batch(p, key.bsk, key.ksk, "NAND", a[:2], b[:2], nthreads=1)
     one = (time.perf_counter() - t0) / 2
     # all cores: size the sample for ~budget_s of wall time, at least one gate per thread
     per_thread = max(1, int(budget_s / max(one * 1.5, 1e-3)))
     S = min(a.shape[0], cores * per_thread)
     t0 = time.perf_counter()
-    _, used = o.gate_batch(p, bsk_f, ksk, "NAND", a[:S], b[:S], nthreads=cores)
+    _, used = o.gate_batch(p, key.bsk, key.ksk, "NAND", a[:S], b[:S], nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": S / dt, "unit": "gates/s", "cores": used, "kind": "port",
             "sample": f"{S} of the same {a.shape[0]} NAND gates, one bootstrap per thread; "
@@ -115,6 +141,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
+    ap.add_argument("--workload", choices=["mixed", "adder"], default="mixed", help="--mode sharded only")
+    ap.add_argument("--gates", type=int, default=0, help="--mode sharded --workload mixed: total gates (default 131072 per rank)")
     args = ap.parse_args()
 
     import torch
@@ -125,19 +154,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if os.environ.get("TFHE_BENCH_SHARE_GPU"):                    # dry run of the N>1 path on a 1-GPU box
+    share = bool(os.environ.get("TFHE_BENCH_SHARE_GPU"))               # dry run of the N>1 path on a 1-GPU box
+    if share:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU dry runs of the N>1 path
-    if world > 1:
+    if world > 1 or args.mode == "sharded":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl" and not share:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:                                                    # two ranks on one GPU cannot form an RCCL communicator
+            backend = "gloo"
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     def barrier():
         if dist:
@@ -150,22 +182,28 @@ def main():
     pkg = graft.load_package()
     p = pkg.params.Security128Bit
 
-    # ---- synthetic random-key data (no secret key needed: throughput is value-independent)
-    rs = np.random.RandomState(0x7F4E0002 + rank)
-
-    def rnd(shape):
-        return rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
-
-    krs = np.random.RandomState(0x7F4E0002)         # same cloud key on every rank (replicated)
-    bsk_torus = krs.randint(0, 2**32, size=(p.n, 2 * p.L, 2, p.N), dtype=np.uint64).astype(np.uint32)
-    ksk = krs.randint(0, 2**32, size=(p.ksk_rows, p.n + 1), dtype=np.uint64).astype(np.uint32)
-    ksk.reshape(p.N * p.t, p.base, p.n + 1)[:, 0, :] = 0      # k = 0 rows are zero (cloudkey.go:104-106)
-    ck = pkg.CloudKey(p, bsk_torus=bsk_torus, ksk=ksk, device=local_rank)
+    # ---- a real seeded cloud key: generated by the harness on every rank (2 s; the ranks need the secret key to
+    # encrypt and check their own shard), uploaded by rank 0 only and replicated as a device blob over RCCL
+    key = SeededKey()
+    if dist and backend == "nccl" and world > 1:
+        from go_tfhe_amd.distributed import broadcast_cloud_key
+        ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank) if rank == 0 else pkg.CloudKey(p, device=local_rank)
+        t0 = time.perf_counter()
+        broadcast_cloud_key(ck.ctx, src=0)
+        key_broadcast_ms = (time.perf_counter() - t0) * 1e3
+    else:
+        ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank)
+        key_broadcast_ms = None
     ctx = ck.ctx
-    a_h, b_h = rnd((BATCH, p.n + 1)), rnd((BATCH, p.n + 1))
+    if args.mode == "sharded":
+        return sharded_mode(args, pkg, p, key, ck, dist, backend, rank, world, dev)
+
+    rs = np.random.RandomState(KEY_SEED + rank)
+    bits_a, bits_b = rs.randint(0, 2, BATCH), rs.randint(0, 2, BATCH)
+    a_h, b_h = key.enc(bits_a, 1000 + 2 * rank), key.enc(bits_b, 1001 + 2 * rank)
     a = torch.from_numpy(a_h.view(np.int32)).to(dev)
     b = torch.from_numpy(b_h.view(np.int32)).to(dev)
-    out = torch.empty_like(a)
+    out = torch.zeros_like(a)
     stream = torch.cuda.current_stream()
 
     def step():
@@ -173,6 +211,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    out.zero_()                                          # the check below reads what the TIMED steps wrote
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -187,10 +227,19 @@ def main():
     ctx.timing_enable(False)
     br_n, br_ms = ctx.timing_read(0)
     ks_n, ks_ms = ctx.timing_read(1)
+
+    # ---- after the timed region: is what it computed right?
+    got = out.cpu().numpy().view(np.uint32)
+    dec_ok = bool(np.array_equal(key.dec(got), ~(bits_a.astype(bool) & bits_b.astype(bool))))
+    sample = [0, BATCH // 2 + 1, BATCH - 1]
+    want, _ = key.o.gate_batch(key.p, key.bsk, key.ksk, "NAND", np.ascontiguousarray(a_h[sample]), np.ascontiguousarray(b_h[sample]))
+    bit_ok = bool(np.array_equal(got[sample], want))
+    ctx.sync()
+    verified = dec_ok and bit_ok
     if dist:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([elapsed, 0.0 if verified else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed, verified = float(tt[0].item()), float(tt[1].item()) == 0.0
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -198,33 +247,137 @@ def main():
         br_avg_ms = br_ms / max(br_n, 1)
         ks_avg_ms = ks_ms / max(ks_n, 1)
         alg = algorithmic_bytes_blind_rotate(p) * BATCH
-        achieved = alg / (br_avg_ms * 1e-3) / 1e9
+        stream_gbs = alg / (br_avg_ms * 1e-3) / 1e9
+        tflops = fp64_flops_per_bootstrap(p) * BATCH / (br_avg_ms * 1e-3) / 1e12
+        traffic = measured_traffic("k_blind_rotate")
         ks_alg = algorithmic_bytes_keyswitch(p) * BATCH
         line = {
             "metric": "gate bootstraps/sec (NAND, 128-bit params)",
             "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "verified": verified,
             "config": {"workload": "BASELINE configs[1]: batch of 1024 independent NAND bootstraps per GPU, "
                                    "128-bit params (n=700, N=1024, L=3, Bgbit=6, t=9), keys+inputs resident in HBM",
-                       "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)"},
-            "roofline": {"kernel": "k_blind_rotate", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("k_blind_rotate"),
-                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": br_avg_ms, "launches": br_n,
-                         "note": "all 1024 bootstraps stream the same key, four per workgroup in step: each XCD's L2 fetches "
-                                 "it once (traffic = 8 x 68.8 MB), so algorithmic GB/s exceeds the HBM peak; the kernel "
-                                 "is fp64-VALU/LDS bound",
-                         "fp64_tflops": fp64_flops_per_bootstrap(p) * BATCH / (br_avg_ms * 1e-3) / 1e12,
-                         "fp64_vector_peak_tflops": FP64_VECTOR_PEAK_TFLOPS},
+                       "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)",
+                       "inputs": "real encryptions of random bits under a seeded key (harness PRNG)"},
+            "roofline": {"kernel": "k_blind_rotate", "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "flops_per_launch": fp64_flops_per_bootstrap(p) * BATCH,
+                         "avg_launch_ms": br_avg_ms, "launches": br_n,
+                         "hbm_streaming": {"algorithmic_bytes_per_launch": alg, "algorithmic_GBps": stream_gbs,
+                                           "x_hbm_peak": stream_gbs / HBM_PEAK_GBS, "hbm_peak_GBps": HBM_PEAK_GBS,
+                                           "measured_bytes_per_launch": traffic,
+                                           "reuse_factor": (alg / traffic) if traffic else None},
+                         "note": "SURVEY 8d's streaming model (every bootstrap reads the whole 68.8 MB key) does not bound this "
+                                 "kernel: the 1024 bootstraps of a launch walk the key in step and each XCD's L2 fetches it once "
+                                 "(measured traffic = 8 x 68.8 MB), so the algorithmic rate exceeds the HBM peak; the binding "
+                                 "resource is fp64 vector issue (163.4 Mflop per bootstrap)"},
+            "verification": {"all_1024_decrypt_to_NAND": dec_ok, "sampled_outputs_bit_identical_to_oracle": bit_ok,
+                             "sample": sample, "of": "the output buffer the last timed step wrote (zeroed before the timed region)"},
             "kernels": {"k_blind_rotate_ms": br_avg_ms, "k_extract_keyswitch_ms": ks_avg_ms,
                         "keyswitch_algorithmic_GBps": ks_alg / (ks_avg_ms * 1e-3) / 1e9 if ks_n else None},
         }
+        if key_broadcast_ms is not None:
+            line["key_broadcast_ms"] = key_broadcast_ms
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(p, a_h, b_h, bsk_torus, ksk)
+            line["cpu_baseline"] = cpu_baseline(key, a_h, b_h)
         print(json.dumps(line), flush=True)
     ck.close()
     if dist:
         dist.destroy_process_group()
+
+
+def sharded_mode(args, pkg, p, key, ck, dist, backend, rank, world, dev):
+    """Root holds the batch; scatter -> local path -> gather is the timed region."""
+    import torch
+    from go_tfhe_amd.distributed import ShardedGates, ShardedCircuits, gpu_compute
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor, balance_levels, count_gates
+    n1 = p.n + 1
+    cdev = dev if backend == "nccl" else "cpu"              # gloo moves host tensors: stage through the host in dry runs
+    rs = np.random.RandomState(KEY_SEED)
+
+    def to_c(t):
+        return t if backend == "nccl" else t.cpu()
+
+    def local(fn):
+        if backend == "nccl":
+            return fn
+        return lambda *xs: fn(*[x.to(dev) if hasattr(x, "to") else x for x in xs]).cpu()
+
+    phases, checks = [], {}
+    if args.workload == "mixed":
+        total = args.gates or 131072 * world
+        eng = ShardedGates(local(gpu_compute(ck.ctx)), n1, device=cdev)
+        if rank == 0:
+            pool_bits = rs.randint(0, 2, 256)
+            pool = torch.from_numpy(key.enc(pool_bits, 77).view(np.int32)).to(dev)
+            ia, ib, ic = (torch.from_numpy(rs.randint(0, 256, total)).to(dev) for _ in range(3))
+            names = np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, total)]       # AND, OR, XOR, MUX
+            ops = torch.from_numpy(names).to(dev)
+            a, b, c = to_c(pool[ia]), to_c(pool[ib]), to_c(pool[ic])
+            ops_c = to_c(ops)
+            run = lambda: eng.gate_batch(ops_c, a, b, c)
+        else:
+            run = lambda: eng.gate_batch(None, None, None, None)
+        units, unit_name = total, "gates"
+    else:
+        C, bits = 256, 8
+        levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+        ex = CircuitExecutor(ck.ctx, balance_levels(levels, max(1, 1024 // max(1, C // world))), n_wires)
+        eng = ShardedCircuits(local(ex.run), n_wires, n1, device=cdev)
+        in_wires = list(range(2 * bits)) + [adder_constant_wire(bits)]
+        out_wires = sums + [cout]
+        if rank == 0:
+            av, bv = rs.randint(0, 256, C), rs.randint(0, 256, C)
+            inp = np.zeros((len(in_wires), C, n1), np.uint32)
+            for i in range(bits):
+                inp[i] = key.enc((av >> i) & 1, 200 + i)
+                inp[bits + i] = key.enc((bv >> i) & 1, 300 + i)
+            inp[2 * bits] = pkg.gates.Constant(False, key.p)
+            inp_t = to_c(torch.from_numpy(inp.view(np.int32)).to(dev))
+            run = lambda: eng.run(in_wires, out_wires, inp_t)
+        else:
+            run = lambda: eng.run(in_wires, out_wires)
+        units, unit_name = count_gates(levels) * C, "gates"
+    res = None
+    for _ in range(max(1, args.warmup)):
+        res = run()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = run()
+        phases.append(dict(eng.last_timing))
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed] + [sum(ph[k] for ph in phases) for k in ("scatter_s", "compute_s", "gather_s")], dtype=torch.float64)
+    if backend == "nccl":
+        tt = tt.to(dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        r = res.cpu().numpy().view(np.uint32) if backend == "nccl" else res.numpy().view(np.uint32)
+        if args.workload == "mixed":
+            A, Bb, Cc = (pool_bits[x.cpu().numpy()].astype(bool) for x in (ia, ib, ic))
+            want = np.where(names == 1, A & Bb, np.where(names == 2, A | Bb, np.where(names == 3, A ^ Bb, np.where(A, Bb, Cc))))
+            sel = np.arange(0, total, max(1, total // 4096))
+            checks["sampled_decrypts_correct"] = bool(np.array_equal(key.dec(np.ascontiguousarray(r[sel])), want[sel]))
+            nb = int((names == 10).sum()) * 3 + int((names != 10).sum())
+            extra = {"bootstraps": nb, "bootstraps_per_s": nb * args.steps / float(tt[0])}
+        else:
+            got = sum(key.dec(np.ascontiguousarray(r[i])).astype(np.int64) << i for i in range(8)) + (key.dec(np.ascontiguousarray(r[8])).astype(np.int64) << 8)
+            checks["all_sums_correct"] = bool(np.array_equal(got, av + bv))
+            extra = {"circuits": 256, "additions_per_s": 256 * args.steps / float(tt[0])}
+        line = {"metric": "gate bootstraps/sec, batch held by rank 0 (scatter + compute + gather timed)", "mode": "sharded",
+                "workload": {"mixed": "BASELINE config 5: mixed AND/OR/XOR/MUX stream", "adder": "BASELINE config 3: 8-bit ripple-carry adder (40 gates) x 256 circuits, sharded by circuit"}[args.workload],
+                "value": units * args.steps / float(tt[0]), "unit": f"{unit_name}/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": float(tt[0]) * 1e3 / args.steps, "backend": backend,
+                "scatter_ms_per_step": float(tt[1]) * 1e3 / args.steps, "compute_ms_per_step": float(tt[2]) * 1e3 / args.steps,
+                "gather_ms_per_step": float(tt[3]) * 1e3 / args.steps, "scaling": "strong", "verified": all(checks.values()),
+                "checks": checks, **extra}
+        print(json.dumps(line), flush=True)
+    ck.close()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

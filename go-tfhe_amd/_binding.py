@@ -58,6 +58,9 @@ def load_library():
         "tfhe_load_ksk": [vp, u32p],
         "tfhe_keygen_cloud": [vp, u32p, u32p, C.c_double, C.c_double, C.c_uint64],
         "tfhe_ctx_reserve": [vp, C.c_int, C.c_int],
+        "tfhe_key_size": [vp, C.c_int, C.POINTER(C.c_size_t)],
+        "tfhe_key_export_dev": [vp, C.c_int, vp, vp],
+        "tfhe_key_import_dev": [vp, C.c_int, vp, vp],
         "tfhe_keygen_cloud_seeded": [vp, u32p, u32p, C.c_double, C.c_double, C.POINTER(C.c_uint64)],
         "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
         "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
@@ -340,6 +343,24 @@ class Context:
     def sync(self):
         """Wait for the context's work and report op codes the device rejected (tfhe_ctx_sync)."""
         self._check(self._lib.tfhe_ctx_sync(self._h))
+
+    def key_size(self, which):
+        n = C.c_size_t()
+        self._check(self._lib.tfhe_key_size(self._h, int(which), C.byref(n)))
+        return n.value
+
+    def key_export_dev(self, which, stream=None):
+        """The loaded key `which` (0 = bootstrapping, 1 = key-switching) as an opaque uint8 GPU tensor."""
+        import torch
+        blob = torch.empty(self.key_size(which), dtype=torch.uint8, device=torch.device("cuda", self.device))
+        self._check(self._lib.tfhe_key_export_dev(self._h, int(which), C.c_void_p(blob.data_ptr()), self._stream(stream)))
+        return blob
+
+    def key_import_dev(self, which, blob, stream=None):
+        if not blob.is_cuda or not blob.is_contiguous() or blob.numel() * blob.element_size() != self.key_size(which) \
+                or blob.device.index != self.device:
+            raise ValueError("key blob: need a contiguous tensor of key_size(which) bytes on the context's GPU")
+        self._check(self._lib.tfhe_key_import_dev(self._h, int(which), C.c_void_p(blob.data_ptr()), self._stream(stream)))
 
     def reserve(self, max_batch, with_mux=False):
         """Pre-size the intermediate buffers (needed before capturing _dev calls into a graph)."""

@@ -715,6 +715,53 @@ int tfhe_keygen_cloud_seeded(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1
     return TFHE_OK;
 }
 
+// ---- device-layout key blobs (replication across GPUs, save / restore) ------------------------------------
+namespace {
+size_t ksk_device_bytes(const tfhe_ctx *c) { return (ksk_rows_packed(c->P) + 1) * (size_t)c->n1p * sizeof(uint32_t); }
+}
+
+int tfhe_key_size(tfhe_ctx *c, int which, size_t *bytes)
+{
+    if (!c || !bytes || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    *bytes = which == 0 ? bsk_elems(c->P) * sizeof(cd) : ksk_device_bytes(c);
+    return TFHE_OK;
+}
+
+int tfhe_key_export_dev(tfhe_ctx *c, int which, void *d_dst, void *stream)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!d_dst || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (which == 0 ? !c->have_bsk : !c->have_ksk) return fail(TFHE_E_NOKEY, "key not loaded");
+    size_t bytes;
+    tfhe_key_size(c, which, &bytes);
+    HIP_TRY(hipMemcpyAsync(d_dst, which == 0 ? c->bsk.p : c->ksk.p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return TFHE_OK;
+}
+
+int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, void *stream)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!d_src || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    size_t bytes;
+    tfhe_key_size(c, which, &bytes);
+    hipStream_t st = (hipStream_t)stream;
+    if (which == 0) {
+        if ((rc = c->bsk.reserve(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->bsk.p, d_src, bytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = make_quad_key(c, st))) return rc;
+        c->have_bsk = true;
+    } else {
+        if ((rc = c->ksk.reserve(bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->ksk.p, d_src, bytes, hipMemcpyDeviceToDevice, st));
+        c->have_ksk = true;
+    }
+    return TFHE_OK;
+}
+
 int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
                       uint64_t seed)
 {

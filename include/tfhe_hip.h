@@ -122,6 +122,17 @@ int tfhe_keygen_cloud_seeded(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *
 int tfhe_keygen_cloud(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *s1, double alpha_lv0,
                       double alpha_lv1, uint64_t seed);
 
+/* The loaded keys as opaque device-layout blobs: CloudKey (cloudkey.go:16-21) has no serialised form in the
+ * reference; this is the engine's.  which: 0 = bootstrapping key (wave-native spectra, same byte count as the
+ * reference's [n][2L][2][N] float64), 1 = key-switching key (packed, zero rows dropped).  Export copies the blob to
+ * caller-owned DEVICE memory of tfhe_key_size bytes, import installs one (and derives what the engine derives
+ * at load time) -- both enqueue on `stream`.  A blob is only meaningful to a context with the SAME parameters and
+ * the same library build.  Uses: replicate a key from GPU 0 to the other GPUs of a node with one RCCL broadcast
+ * per key instead of N uploads / regenerations, or park it in host memory between runs. */
+int tfhe_key_size(tfhe_ctx *ctx, int which, size_t *bytes);
+int tfhe_key_export_dev(tfhe_ctx *ctx, int which, void *d_dst, void *stream);
+int tfhe_key_import_dev(tfhe_ctx *ctx, int which, const void *d_src, void *stream);
+
 /* Evaluator.BootstrapAssign / BootstrapLUTAssign over a batch (evaluator.go:139-148,
  * programmable_bootstrap.go:93-115; batch fan-out trgsw.go:234-252).
  *   in      [B][n+1]

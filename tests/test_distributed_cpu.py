@@ -52,11 +52,49 @@ def _worker(rank, world, port, q):
         ok = ok and np.array_equal(got2.numpy().view(np.uint32), want2)
         got3 = eng.gate_batch("NAND", ta[:1], tb[:1])           # batch smaller than the world
         ok = ok and np.array_equal(got3.numpy().view(np.uint32), want2[:1])
+        got4 = eng.gate_batch(torch.from_numpy(ops[:6]), ta[:6], tb[:6], tc[:6])     # even shards: strided packing path
+        ok = ok and np.array_equal(got4.numpy().view(np.uint32), want[:6])
+        pk = eng.pack("NAND", ta, tb)                                                # pre-packed by the caller
+        got5 = eng.gate_batch(None, None, None, packed=pk)
+        ok = ok and np.array_equal(got5.numpy().view(np.uint32), want2)
+        ok = ok and set(eng.last_timing) == {"scatter_s", "compute_s", "gather_s"}
+    else:
+        for _ in range(5):
+            eng.gate_batch(None, None, None, None)
+    # ---- a circuit sharded BY CIRCUIT: 2-bit reference-form adder (10 gates, Constant(false) carry-in), 4 circuits
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire
+    from go_tfhe_amd.distributed import ShardedCircuits
+    bits, C = 2, 4
+    levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+
+    def run_local(wires):
+        w = wires.numpy().view(np.uint32)
+        for lvl in levels:
+            for (op, x, y, z, out) in lvl:
+                res, _ = o.gate_batch(ks.p, ks.bsk, ks.ksk, op, np.ascontiguousarray(w[x]), np.ascontiguousarray(w[y]), nthreads=1)
+                w[out] = res
+        return wires
+
+    circ = ShardedCircuits(run_local, n_wires, n1)
+    in_wires = list(range(2 * bits)) + [adder_constant_wire(bits)]
+    out_wires = sums + [cout]
+    if rank == 0:
+        av, bv = np.array([0, 1, 2, 3]), np.array([3, 3, 1, 2])
+        inp = np.zeros((len(in_wires), C, n1), np.uint32)
+        for i in range(bits):
+            inp[i] = ks.enc((av >> i) & 1)
+            inp[bits + i] = ks.enc((bv >> i) & 1)
+        inp[2 * bits] = pkg.gates.Constant(False, ks.p)
+        res = circ.run(in_wires, out_wires, torch.from_numpy(inp.view(np.int32))).numpy().view(np.uint32)
+        got = sum(ks.dec(res[i]).astype(np.int64) << i for i in range(bits)) + (ks.dec(res[bits]).astype(np.int64) << bits)
+        ok = ok and np.array_equal(got, av + bv)
+        full = torch.zeros((n_wires, C, n1), dtype=torch.int32)                       # unsharded run: identical wires
+        full[torch.tensor(in_wires)] = torch.from_numpy(inp.view(np.int32))
+        run_local(full)
+        ok = ok and np.array_equal(full[torch.tensor(out_wires)].numpy().view(np.uint32), res)
         q.put(ok)
     else:
-        eng.gate_batch(None, None, None, None)
-        eng.gate_batch(None, None, None, None)
-        eng.gate_batch(None, None, None, None)
+        circ.run(in_wires, out_wires)
     dist.barrier()
     dist.destroy_process_group()
 

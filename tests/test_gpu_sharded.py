@@ -37,5 +37,23 @@ def test_sharded_gates_nccl_single_node(oracle, keys_small, ck_small, pkg):
         got2 = eng.gate_batch("XNOR", ta, tb)
         want2, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, "XNOR", a, b)
         assert np.array_equal(got2.cpu().numpy().view(np.uint32), want2)
+        assert set(eng.last_timing) == {"scatter_s", "compute_s", "gather_s"}
+        # key replication: the broadcast helper (a one-rank broadcast here) and the blob round trip it is made of --
+        # a second context that only ever IMPORTS the two device-layout blobs computes identical ciphertexts
+        from go_tfhe_amd.distributed import broadcast_cloud_key
+        from conftest import gpu_params
+        broadcast_cloud_key(ck_small.ctx, src=0)
+        ck2 = pkg.CloudKey(gpu_params(pkg, k.p))
+        with pytest.raises(pkg.TfheError):
+            ck2.ctx.gate_batch("NAND", a, b)                      # no key yet
+        for which in (0, 1):
+            blob = ck_small.ctx.key_export_dev(which)
+            assert blob.numel() == ck_small.ctx.key_size(which)
+            ck2.ctx.key_import_dev(which, blob)
+        torch.cuda.synchronize()
+        for B in (37, 300):                                       # both blind-rotate layouts of the imported key
+            idx = np.arange(B) % 37
+            assert np.array_equal(ck2.ctx.gate_batch("XNOR", a[idx], b[idx]), want2[idx])
+        ck2.close()
     finally:
         dist.destroy_process_group()
