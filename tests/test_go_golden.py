@@ -1,0 +1,114 @@
+"""Vectors produced by the Go reference ITSELF (tools/go_golden/main.go) against the C oracle (CPU tier) and the
+HIP engine (-m gpu).  This is the test that pins parity at ciphertext level.
+
+The build image has no Go toolchain, so tests/golden/go/ is empty in this repository and every test here SKIPS with
+"parity unpinned": the oracle is a restatement checked against exact integer arithmetic and the reference's own
+known answers, not against the Go binary.  The first person with Go runs the recipe in tools/go_golden/main.go,
+commits small/*.npy into tests/golden/go/, and these tests start to bite; the full-key vectors (172 MB) are read
+from $TFHE_GO_GOLDEN_BIG when set.
+"""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SMALL = os.environ.get("TFHE_GO_GOLDEN_SMALL", os.path.join(HERE, "golden", "go"))
+BIG = os.environ.get("TFHE_GO_GOLDEN_BIG", os.path.join(SMALL, "big"))
+
+have_small = os.path.exists(os.path.join(SMALL, "extprod_out.npy"))
+have_big = os.path.exists(os.path.join(BIG, "lwe_out.npy"))
+need_small = pytest.mark.skipif(not have_small, reason="parity unpinned: no Go-generated vectors in tests/golden/go "
+                                                       "(tools/go_golden/main.go needs a Go toolchain)")
+need_big = pytest.mark.skipif(not (have_small and have_big), reason="parity unpinned: no full-key Go vectors ($TFHE_GO_GOLDEN_BIG)")
+
+GATES2 = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
+
+
+def load(d, name):
+    return np.load(os.path.join(d, name + ".npy"))
+
+
+def go_params(oracle):
+    n, N, Nbit, L, Bgbit, basebit, t, offset = (int(x) for x in load(SMALL, "params"))
+    p = oracle.params("128")
+    assert (p.n, p.N, p.Nbit, p.L, p.Bgbit, p.basebit, p.t) == (n, N, Nbit, L, Bgbit, basebit, t)
+    assert oracle.offset(p) == offset                     # cloudkey.go:60-71
+    return p
+
+
+# ------------------------------------------------------------------------------- CPU tier: oracle vs Go
+@need_small
+def test_oracle_external_product_equals_go(oracle):
+    p = go_params(oracle)
+    got = oracle.external_product(p, load(SMALL, "extprod_trgsw"), load(SMALL, "extprod_in"))
+    assert np.array_equal(got, load(SMALL, "extprod_out"))
+
+
+@need_small
+def test_oracle_cmux_chain_equals_go(oracle):
+    p = go_params(oracle)
+    keys, lwe, acc = load(SMALL, "cmux_trgsw"), load(SMALL, "cmux_lwe"), load(SMALL, "cmux_acc")
+    K = keys.shape[0]
+    pk = p.small(K)                                       # the chain uses the first K mask words and the body
+    ct = np.concatenate([lwe[:K], lwe[-1:]]).astype(np.uint32)
+    tv = oracle.gate_testvec(p)
+    for steps in range(K + 1):
+        assert np.array_equal(oracle.blind_rotate(pk, keys, ct, tv, steps), acc[steps]), steps
+
+
+@need_big
+def test_oracle_bootstrap_and_gates_equal_go(oracle):
+    p = go_params(oracle)
+    bsk, ksk = load(BIG, "bsk_fourier"), load(BIG, "ksk")
+    tv = oracle.gate_testvec(p)
+    cts = load(BIG, "lwe_in")
+    for b in range(min(2, cts.shape[0])):                 # 37 ms each on one core
+        acc = oracle.blind_rotate(p, bsk, cts[b], tv)
+        assert np.array_equal(acc, load(BIG, "trlwe_acc")[b])
+        assert np.array_equal(oracle.key_switch(p, ksk, oracle.sample_extract(acc)), load(BIG, "lwe_out")[b])
+    a, bb, c = load(BIG, "gate_a"), load(BIG, "gate_b"), load(BIG, "gate_c")
+    for op in GATES2 + ["MUX"]:
+        got, _ = oracle.gate_batch(p, bsk, ksk, op, a[:2], bb[:2], c[:2] if op == "MUX" else None)
+        assert np.array_equal(got, load(BIG, "gate_" + op)[:2]), op
+    s0 = load(BIG, "key_lv0")
+    assert np.array_equal(oracle.decrypt_bools(p, s0, load(BIG, "lwe_out")), load(BIG, "bits").astype(bool))
+
+
+# ------------------------------------------------------------------------------- GPU tier: HIP engine vs Go
+@pytest.mark.gpu
+@need_small
+def test_gpu_external_product_and_chain_equal_go(oracle, pkg):
+    from conftest import gpu_params
+    p = go_params(oracle)
+    keys, lwe, acc = load(SMALL, "cmux_trgsw"), load(SMALL, "cmux_lwe"), load(SMALL, "cmux_acc")
+    K = keys.shape[0]
+    pk = p.small(K)
+    ksk = np.zeros((pk.N * pk.t * (1 << pk.basebit), pk.n + 1), np.uint32)
+    ck = pkg.CloudKey(gpu_params(pkg, pk), bsk_fourier=np.ascontiguousarray(keys), ksk=ksk)
+    ct = np.concatenate([lwe[:K], lwe[-1:]]).astype(np.uint32)[None, :]
+    for steps in range(K + 1):
+        assert np.array_equal(ck.ctx.blind_rotate_batch(ct, None, steps)[0], acc[steps]), steps
+    ck.close()
+    p1 = p.small(1)
+    ck = pkg.CloudKey(gpu_params(pkg, p1), bsk_fourier=np.ascontiguousarray(load(SMALL, "extprod_trgsw")[None]),
+                      ksk=np.zeros((p1.N * p1.t * (1 << p1.basebit), 2), np.uint32))
+    got = ck.ctx.external_product_batch(0, load(SMALL, "extprod_in")[None])[0]
+    assert np.array_equal(got, load(SMALL, "extprod_out"))
+    ck.close()
+
+
+@pytest.mark.gpu
+@need_big
+def test_gpu_bootstrap_and_gates_equal_go(oracle, pkg):
+    from conftest import gpu_params
+    p = go_params(oracle)
+    ck = pkg.CloudKey(gpu_params(pkg, p), bsk_fourier=load(BIG, "bsk_fourier"), ksk=load(BIG, "ksk"))
+    cts = load(BIG, "lwe_in")
+    assert np.array_equal(ck.ctx.blind_rotate_batch(cts), load(BIG, "trlwe_acc"))
+    assert np.array_equal(ck.ctx.bootstrap_batch(cts), load(BIG, "lwe_out"))
+    a, b, c = load(BIG, "gate_a"), load(BIG, "gate_b"), load(BIG, "gate_c")
+    for op in GATES2:
+        assert np.array_equal(ck.ctx.gate_batch(op, a, b), load(BIG, "gate_" + op)), op
+    assert np.array_equal(ck.ctx.gate_batch("MUX", a, b, c), load(BIG, "gate_MUX"))
+    ck.close()

@@ -91,3 +91,77 @@ def test_keygen_rejects_bad_input(pkg):
     with pytest.raises(pkg.TfheError):
         ctx.keygen_cloud(s0, s1, 1e-5, 1e-8, 1)
     ctx.close()
+
+
+def _wave_blob_to_reference_spectra(blob, n, L):
+    """Device layout cd bsk[n][2][L][2][8][64] (csrc/kernels.hpp) -> reference FourierPoly layout [n][2L][2][1024]:
+    (reg, lane) holds root u = (lane>>3) + 8*(lane&7) + 64*reg, the reference keeps it in slot bitrev9(-u mod 512),
+    stored as blocks of [4 re | 4 im] (poly.go:57-62)."""
+    z = blob.view(np.float64).reshape(n, 2, L, 2, 8, 64, 2)
+    reg, lane = np.meshgrid(np.arange(8), np.arange(64), indexing="ij")
+    u = (lane >> 3) + 8 * (lane & 7) + 64 * reg
+    v = (512 - u) & 511
+    slot = np.zeros_like(v)
+    for b in range(9):
+        slot |= ((v >> b) & 1) << (8 - b)
+    base = 8 * (slot >> 2) + (slot & 3)
+    out = np.zeros((n, 2, L, 2, 1024), np.float64)
+    out[..., base] = z[..., 0]
+    out[..., base + 4] = z[..., 1]
+    return out.reshape(n, 2 * L, 2, 1024)                  # reference row r = p*L + l
+
+
+def _centered(x):
+    return ((x.astype(np.int64) + 2**31) % 2**32) - 2**31
+
+
+def test_keygen_noise_statistics(oracle, pkg):
+    # The one security-relevant property of tfhe_keygen_cloud that decrypt-level tests cannot see: the noise it adds.
+    # The generated keys are read back as device-layout blobs, every ciphertext in them is "decrypted" with the
+    # secret keys and the known plaintext removed; what is left must be the prescribed Gaussian (cloudkey.go:88-145:
+    # KSK rows at alpha_lv0, TRGSW rows at alpha_lv1), not zero and not something else.
+    p = oracle.params("128").small(8)
+    rng = oracle.rng(0x7F4E0044)
+    s0, s1 = oracle.keygen_secret(p, rng)
+    ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=2024)
+    ksk = ck.ctx.key_export_dev(1).cpu().numpy().view(np.uint32)
+    bskb = ck.ctx.key_export_dev(0).cpu().numpy()
+    ck.close()
+    # ---- key-switching key: packed rows [N*t*(base-1) + 1][n1p], row (i, j, k-1) encrypts k*s1[i]*2^(32-(j+1)*basebit) under s0
+    n1p = (p.n + 1 + 3) & ~3
+    rows = ksk.reshape(-1, n1p)[:-1]                        # the last row is the all-zero padding row
+    base1 = (1 << p.basebit) - 1
+    assert rows.shape[0] == p.N * p.t * base1 and rows.shape[0] >= 4096
+    r = np.arange(rows.shape[0])
+    i, j, k = r // (p.t * base1), (r // base1) % p.t, r % base1 + 1
+    msg = (k.astype(np.uint64) * s1[i].astype(np.uint64) << (32 - (j + 1) * p.basebit).astype(np.uint64)) & 0xFFFFFFFF
+    phase = (rows[:, p.n].astype(np.uint64) - (rows[:, :p.n].astype(np.uint64) * s0.astype(np.uint64)).sum(1) - msg) & 0xFFFFFFFF
+    e0 = _centered(phase).astype(np.float64)
+    sigma0 = p.alpha_lv0 * 2.0**32
+    assert abs(e0.mean()) < 5 * sigma0 / np.sqrt(e0.size), e0.mean()
+    assert 0.85 * sigma0 < e0.std() < 1.15 * sigma0, (e0.std(), sigma0)
+    assert 0.64 < np.mean(np.abs(e0) < sigma0) < 0.72            # a Gaussian has 68.3 % within one sigma
+    assert not rows[:, n1p - 1].any() or n1p == p.n + 1              # padding words stay zero
+    # ---- bootstrapping key: TRGSW row r of key i is (A, B = A*s1 + e) + s0[i]*2^(32-(l+1)*Bgbit) on A (r < L) or B (r >= L)
+    spec = _wave_blob_to_reference_spectra(bskb, p.n, p.L)
+    polys = np.stack([oracle.to_poly(x) for x in spec.reshape(-1, p.N)]).reshape(p.n, 2 * p.L, 2, p.N)
+    s1l = s1.astype(np.int64)
+    noise = []
+    for ii in range(p.n):
+        for rr in range(2 * p.L):
+            A, Bp = polys[ii, rr, 0].astype(np.int64), polys[ii, rr, 1].astype(np.int64)
+            mu = (int(s0[ii]) << (32 - (rr % p.L + 1) * p.Bgbit)) & 0xFFFFFFFF
+            if rr < p.L:
+                A[0] = (A[0] - mu) & 0xFFFFFFFF           # the gadget term sits on coefficient 0 of A
+            else:
+                Bp[0] = (Bp[0] - mu) & 0xFFFFFFFF
+            full = np.convolve(A, s1l)                      # exact: |sum| < 2^42
+            As = full[:p.N].copy()
+            As[:p.N - 1] -= full[p.N:]                      # X^N = -1
+            noise.append(_centered((Bp - As) & 0xFFFFFFFF))
+    e1 = np.concatenate(noise).astype(np.float64)
+    sigma1 = p.alpha_lv1 * 2.0**32                          # 85.9 torus units at the 128-bit set
+    assert e1.size >= 4096 and sigma1 > 10
+    assert abs(e1.mean()) < 5 * sigma1 / np.sqrt(e1.size) + 0.6, e1.mean()      # + the truncation of F64ToTorus (toward zero)
+    assert 0.85 * sigma1 < e1.std() < 1.15 * sigma1, (e1.std(), sigma1)
+    assert 0.64 < np.mean(np.abs(e1) < sigma1) < 0.72

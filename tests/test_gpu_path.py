@@ -344,6 +344,29 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
     ck2.close(); ck4.close()
 
 
+def test_committed_golden_vectors_on_gpu(pkg, oracle):
+    # tests/golden/*.npz (inputs + expected outputs, made by tests/golden/make_golden.py and checked there against the
+    # exact-integer product) through the C ABI: one external product at the 128-bit ring/gadget, and a full
+    # tiny-n bootstrap chain (accumulator after blind rotate, LWE after extract + key switch).
+    import os
+    from conftest import KeySet
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gdir, "extprod_N1024_L3_Bg6.npz"))
+    p1 = oracle.params("128").small(1)
+    zero_ksk = lambda p: np.zeros((p.N * p.t * (1 << p.basebit), p.n + 1), np.uint32)
+    ck = pkg.CloudKey(gpu_params(pkg, p1), bsk_torus=np.ascontiguousarray(g["trgsw_torus"][None]), ksk=zero_ksk(p1))
+    assert np.array_equal(ck.ctx.external_product_batch(0, g["trlwe_in"][None])[0], g["trlwe_out"])
+    ck.close()
+    g = np.load(os.path.join(gdir, "bootstrap_n6_seed7F4E0011.npz"))
+    ks = KeySet(oracle, "128", int(g["seed"]), n_override=6)
+    for kw in ({"bsk_fourier": ks.bsk}, {"bsk_torus": ks.bsk_torus}):
+        ck = pkg.CloudKey(gpu_params(pkg, ks.p), ksk=ks.ksk, **kw)
+        assert np.array_equal(ck.ctx.blind_rotate_batch(g["lwe_in"]), g["trlwe_acc"])
+        assert np.array_equal(ck.ctx.extract_keyswitch_batch(g["trlwe_acc"]), g["lwe_out"])
+        assert np.array_equal(ck.ctx.bootstrap_batch(g["lwe_in"]), g["lwe_out"])
+        ck.close()
+
+
 def test_concurrent_host_threads(oracle, keys_small, ck_small, pkg):
     # A Go shim calls from many goroutines (the reference fans batches out over goroutines, trgsw.go:234-252).
     # ctypes drops the GIL, so these threads really overlap: four on one shared context (serialised by its
