@@ -87,9 +87,11 @@ template <int S> __device__ __forceinline__ void dft4(cd (&x)[4])
 // LDS slots (16 B each, 256 per wave) of the three exchanges; (hi, mid, lo) = the lane's three base-4 digits.
 //   exchange 1: element (reg m; lane b,c,d)      at 64m + 16b + 4c + d
 //   exchange 2: element (reg m'; lane m,c,d)     at 64m + 16m' + 4((c+m')&3) + d
-//   exchange 3: element (reg m''; lane m,m',d)   at 64m + 16m' + 4((m''+d)&3) + ((m'+d)&3)
-// Each ds_write_b128 (8 contiguous lanes per pass) and each ds_read_b128 (the four 16-lane service groups of
-// MI355X_MICROARCH.md, LDS) touches every slot residue mod 16 at most once, in both directions.
+//   exchange 3: element (reg m''; lane m,m',d)   at 64m + 16d + 4m' + ((d+m'')&3)
+// In both directions every ds_write_b128 pass (8 contiguous lanes, 32 banks of 4 B: 8 slots) touches each slot
+// residue mod 8 once and every ds_read_b128 service group (the four 16-lane groups of MI355X_MICROARCH.md, 64
+// banks: 16 slots) each residue mod 16 once: SQ_LDS_BANK_CONFLICT = 0 (a first layout of exchange 3 that was only
+// checked mod 16 cost 32 conflict cycles per step on the inverse's stores -- profiles/r02_c_pmc128_quad_summary.txt).
 struct QuadLane {
     int lane, hi, mid, lo;
 };
@@ -167,9 +169,9 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
         for (int c = 1; c < 4; c++) x[t][c] = cmul(x[t][c], tw.w[1][c - 1]);
         dft4<1>(x[t]);
         QUAD_PRIO_HI();
-        QUAD_XF(for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.mid + 4 * ((mpp + q.lo) & 3) + ((q.mid + q.lo) & 3)] = x[t][mpp];)
+        QUAD_XF(for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)] = x[t][mpp];)
         wave_lds_order();
-        QUAD_XF(for (int d = 0; d < 4; d++) x[t][d] = sc[64 * q.hi + 16 * q.mid + 4 * ((q.lo + d) & 3) + ((q.mid + d) & 3)];)
+        QUAD_XF(for (int d = 0; d < 4; d++) x[t][d] = sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)];)
         wave_lds_order();
         QUAD_PRIO_LO();
         QUAD_PIN();
@@ -188,9 +190,9 @@ __device__ __forceinline__ void fft256_inverse(cd (&x)[4], cd *sc, const cd *__r
     dft4<-1>(x);
 #pragma unroll
     for (int d = 1; d < 4; d++) x[d] = cmulc(x[d], tw.w[2][d - 1]);
-    QUAD_XI(for (int d = 0; d < 4; d++) sc[64 * q.hi + 16 * q.mid + 4 * ((q.lo + d) & 3) + ((q.mid + d) & 3)] = x[d];)
+    QUAD_XI(for (int d = 0; d < 4; d++) sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)] = x[d];)
     wave_lds_order();
-    QUAD_XI(for (int mpp = 0; mpp < 4; mpp++) x[mpp] = sc[64 * q.hi + 16 * q.mid + 4 * ((mpp + q.lo) & 3) + ((q.mid + q.lo) & 3)];)
+    QUAD_XI(for (int mpp = 0; mpp < 4; mpp++) x[mpp] = sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)];)
     wave_lds_order();
     dft4<-1>(x);
 #pragma unroll
