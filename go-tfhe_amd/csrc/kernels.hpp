@@ -222,7 +222,12 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
             }
         }
     }
+#ifdef FFT_PIPE
+    if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane);
+    else fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
+#else
     fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
+#endif
 #pragma unroll
     for (int l = 0; l < L; l++) {
 #pragma unroll
@@ -250,11 +255,23 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     // hand the partner's partial sum over
 #pragma unroll
     for (int k = 0; k < 8; k++) sc_mine[k * 64 + lane] = send[k];
+#ifdef FFT_PIPE_SEND
+    // the stores of send[k] go out under the last level's products of the remaining k (8 fp64 per k and output)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+#endif
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
     __syncthreads();
+#ifdef FFT_PIPE_INV
+    fft512_inverse_pipe(keep, sc_mine, table, tw, lane);
+#else
     fft512_inverse(keep, sc_mine, table, tw, lane);
+#endif
     // |v| <= 2L * N * (Bg/2) * 2^31: below 2^51 the 1.5*2^52 trick is exact (L=3, Bgbit=6: 2^48.6);
     // the Uint1 / Uint3 shapes (L=2,Bgbit=10: 2^52; L=1,Bgbit=23: 2^64) need the wide form and sit in
     // the tolerance regime, like the reference's own fp64 pipeline at those sets.

@@ -184,6 +184,78 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
     }
 }
 
+// Software-pipelined form (see fft512_forward_batch_pipe): transform t's exchange is issued inside transform t+1's
+// arithmetic, one DS instruction per QUAD_PIPE_VALU VALU instructions.
+#ifndef QUAD_PIPE_VALU
+#define QUAD_PIPE_VALU 6
+#endif
+template <int NB>
+__device__ __forceinline__ void fft256_forward_batch_pipe(cd (&x)[NB][4], cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw,
+                                                          const QuadLane q)
+{
+    auto xchg = [&](int lvl, int t) {
+        if (lvl == 1) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];
+            wave_lds_order();
+#pragma unroll
+            for (int b = 0; b < 4; b++) x[t][b] = sc[64 * q.hi + 16 * b + (q.lane & 15)];
+        } else if (lvl == 2) {
+#pragma unroll
+            for (int mp = 0; mp < 4; mp++) sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo] = x[t][mp];
+            wave_lds_order();
+#pragma unroll
+            for (int c = 0; c < 4; c++) x[t][c] = sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo];
+        } else {
+#pragma unroll
+            for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)] = x[t][mpp];
+            wave_lds_order();
+#pragma unroll
+            for (int d = 0; d < 4; d++) x[t][d] = sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)];
+        }
+        wave_lds_order();
+    };
+    auto level = [&](int lvl, int t) {
+        if (lvl == 1) {
+#pragma unroll
+            for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], T[a]);
+        } else {
+#pragma unroll
+            for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], tw.w[lvl - 2][a - 1]);
+        }
+        dft4<1>(x[t]);
+    };
+    auto mix = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, QUAD_PIPE_VALU, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, QUAD_PIPE_VALU, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    level(1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int lvl = 1; lvl <= 4; lvl++) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) {
+            if (lvl == 1 && t == 0) continue;
+            // the exchange that precedes this piece of arithmetic in the pipeline: previous transform of this level,
+            // or the last transform of the previous level
+            if (t > 0 && lvl < 4) xchg(lvl, t - 1);
+            else if (t == 0) xchg(lvl - 1, NB - 1);
+            level(lvl, t);
+            if ((t > 0 && lvl < 4) || t == 0) mix();
+        }
+    }
+}
+
 // Inverse (includes the 1/512 of the whole 512-point transform): spectrum order in, x[a] = y_h[64a + lane] / 2 out.
 __device__ __forceinline__ void fft256_inverse(cd (&x)[4], cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q)
 {
@@ -324,7 +396,12 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
                 x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
             }
         }
+#ifdef QUAD_PIPE
+        if constexpr (L > 1) fft256_forward_batch_pipe<L>(x, sc, T, tw, q);
+        else fft256_forward_batch<L>(x, sc, T, tw, q);
+#else
         fft256_forward_batch<L>(x, sc, T, tw, q);
+#endif
         cd keep[4], send[4];
 #pragma unroll
         for (int l = 0; l < L; l++) {

@@ -72,6 +72,19 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 // early and its latency overlaps the other waves' fp64 work: -4 % blind-rotate time on the batched forward
 // exchanges; the same on the inverse / partner exchanges measured +3 %, so only the forward path uses it.
 #define TFHE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+// LDS-exchange scheduling (r02; A/B on one box, tools/ab_bench.py): the exchanges' DS instructions are spread
+// through the arithmetic with sched_group_barrier instead of being issued in bursts -- the waves of these kernels
+// spend ~20 % of their cycles stalled on the LDS instruction queue (SQ_WAIT_INST_LDS), a burst of ds_write_b128
+// fills it.  k_blind_rotate<3,6,4> x1024: 6.34 -> 6.11 ms; k_blind_rotate_2048 x512: 6.98 -> 6.79 ms;
+// k_blind_rotate_quad x128: 3.19 -> 3.10 ms.  -DFFT_NO_PIPE restores the burst form (the A/B baseline).
+#ifndef FFT_NO_PIPE
+#define FFT_PIPE
+#define FFT_PIPE1
+#define QUAD_PIPE
+#endif
+#ifndef FFT_PIPE_VALU
+#define FFT_PIPE_VALU 10
+#endif
 
 __device__ __forceinline__ void wave_lds_order()
 {
@@ -206,10 +219,33 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
 }
 
 // The same transforms with the derived powers supplied by the caller (TwStep), no rebuild inside.
+// Single transforms (one forward, one inverse per wave and step: the N = 2048 blind rotate).  With -DFFT_PIPE1
+// every exchange's stores are issued one by one under the tail of the arithmetic that produces them
+// (sched_group_barrier) instead of as a burst of eight after it.
+#ifdef FFT_PIPE1
+#define FFT_MIX1(first)                                                           \
+    do {                                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x2, first, 0);                      \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) {                        \
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x2, FFT_PIPE1_VALU, 0);         \
+        }                                                                         \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                        \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#define FFT_MIX1_BEGIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef FFT_PIPE1_VALU
+#define FFT_PIPE1_VALU 3
+#endif
+#else
+#define FFT_MIX1(first)
+#define FFT_MIX1_BEGIN()
+#endif
 __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                const LaneTwiddles &tw, const TwStep &ts, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
+    FFT_MIX1_BEGIN();
 #pragma unroll
     for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
     dft8<1>(x);
@@ -219,6 +255,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
     wave_lds_order();
+    FFT_MIX1(64);
     twist_all(x, tw.l2, ts.l2);
     dft8<1>(x);
 #pragma unroll
@@ -227,6 +264,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
     wave_lds_order();
+    FFT_MIX1(64);
     twist_all(x, tw.l3, ts.l3);
     dft8<1>(x);
 }
@@ -234,6 +272,7 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
                                                const LaneTwiddles &tw, const TwStep &ts, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
+    FFT_MIX1_BEGIN();
     dft8<-1>(x);
     twist_all_conj(x, tw.l3, ts.l3);
 #pragma unroll
@@ -242,6 +281,7 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
     wave_lds_order();
+    FFT_MIX1(64);
     dft8<-1>(x);
     twist_all_conj(x, tw.l2, ts.l2);
 #pragma unroll
@@ -250,6 +290,7 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
     wave_lds_order();
+    FFT_MIX1(64);
     dft8<-1>(x);
 #pragma unroll
     for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
@@ -301,6 +342,74 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
     }
 }
 
+// Software-pipelined form of fft512_forward_batch (experiment, -DFFT_PIPE): transform t's exchange (8 stores + 8
+// loads) is issued INSIDE transform t+1's arithmetic, one DS instruction per few fp64 instructions
+// (sched_group_barrier), instead of one burst of 24 + 24 after all three transforms' arithmetic.  Rationale:
+// PMC shows the waves of k_blind_rotate spend ~20 % of their cycles stalled on the LDS instruction queue
+// (SQ_WAIT_INST_LDS): a burst of ds_write_b128 fills it and blocks the wave, an interleaved stream does not.
+template <int NB>
+__device__ __forceinline__ void fft512_forward_batch_pipe(cd (&x)[NB][8], cd *sc, const cd *__restrict__ table,
+                                                          const LaneTwiddles &tw, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    auto xchg1 = [&](int t) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];
+        wave_lds_order();
+#pragma unroll
+        for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];
+        wave_lds_order();
+    };
+    auto xchg2 = [&](int t) {
+#pragma unroll
+        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];
+        wave_lds_order();
+#pragma unroll
+        for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];
+        wave_lds_order();
+    };
+    auto mix = [&]() {          // the region just written: 1 DS op per FFT_PIPE_VALU VALU ops, stores first
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, FFT_PIPE_VALU, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, FFT_PIPE_VALU, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto level1 = [&](int t) {
+#pragma unroll
+        for (int a = 1; a < 8; a++) x[t][a] = cmul(x[t][a], table[a]);
+        dft8<1>(x[t]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    level1(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < NB; t++) { xchg1(t - 1); level1(t); mix(); }
+    const TwAll a2 = expand_pow(tw.l2);
+    // level 2 of transform t runs over the exchange of the previous one (the last exchange of level 1 first)
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        if (t == 0) xchg1(NB - 1); else xchg2(t - 1);
+        twist_all(x[t], tw.l2, a2);
+        dft8<1>(x[t]);
+        mix();
+    }
+    const TwAll a3 = expand_pow(tw.l3);
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        if (t == 0) { xchg2(NB - 1); }
+        twist_all(x[t], tw.l3, a3);
+        dft8<1>(x[t]);
+        if (t == 0) mix();
+    }
+}
+
 // Inverse transform (includes the 1/512 scale); spectrum order in, x[a] = z_{64a+lane} out.
 __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                const LaneTwiddles &tw, int lane)
@@ -324,6 +433,46 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
     wave_lds_order();
+    dft8<-1>(x);
+#pragma unroll
+    for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
+}
+
+// fft512_inverse with each exchange's stores issued as soon as their value is final (one ds_write_b128 per twisted
+// output, under the remaining twists) instead of in one burst of eight; same arithmetic.  (-DFFT_PIPE_INV)
+__device__ __forceinline__ void fft512_inverse_pipe(cd (&x)[8], cd *sc, const cd *__restrict__ table,
+                                                    const LaneTwiddles &tw, int lane)
+{
+    const int hi = lane >> 3, lo = lane & 7;
+    auto mix = [&]() {
+        __builtin_amdgcn_sched_group_barrier(0x2, 76, 0);            // the 8-point DFT and the first twists
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    dft8<-1>(x);
+    twist_pow<true>(x, tw.l3);
+#pragma unroll
+    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    wave_lds_order();
+#pragma unroll
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    wave_lds_order();
+    mix();
+    dft8<-1>(x);
+    twist_pow<true>(x, tw.l2);
+#pragma unroll
+    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    wave_lds_order();
+#pragma unroll
+    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    wave_lds_order();
+    mix();
     dft8<-1>(x);
 #pragma unroll
     for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
