@@ -223,8 +223,19 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         }
     }
 #ifdef FFT_PIPE
-    if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane);
+#ifdef LATE_KEYS
+    // level-0 key slices are requested here, under the last level of the forward transforms (~260 fp64
+    // instructions), instead of a whole step ahead: 64 VGPRs free during the inverse transform and levels 1-2
+    if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane, [&] {
+        __builtin_amdgcn_sched_barrier(0);
+        load_keys(K, key_ip, p, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    else { load_keys(K, key_ip, p, lane); fft512_forward_batch<L>(x, sc_mine, table, tw, lane); }
+#else
+    if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane, [] {});
     else fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
+#endif
 #else
     fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
 #endif
@@ -249,7 +260,9 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         }
         __builtin_amdgcn_sched_barrier(0);
         if (l + 1 < L) load_keys(K, key_ip + (size_t)(l + 1) * 2 * 512, p, lane);
+#ifndef LATE_KEYS
         else if (key_next) load_keys(K, key_next, p, lane);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     // hand the partner's partial sum over
@@ -338,7 +351,9 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
     constexpr size_t kStep = (size_t)2 * L * 2 * 512;        // cd elements per CMUX step
     const int nsteps = A.nsteps;
     KeyRegs K;
+#ifndef LATE_KEYS
     if (nsteps > 0) load_keys(K, key, p, lane);
+#endif
     for (int i = 0; i < nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
@@ -374,7 +389,9 @@ __global__ __launch_bounds__(128, 2) void k_external_product(const cd *bsk, cons
     const DiffSource S{nullptr, 0, src};
     const cd *key = bsk + ((size_t)key_index * 2 + p) * L * 2 * 512;
     KeyRegs K;
+#ifndef LATE_KEYS
     load_keys(K, key, p, lane);
+#endif
     external_product_core<L, BGBIT>(S, e, key, nullptr, K, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
     uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
 #pragma unroll
