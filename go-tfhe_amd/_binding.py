@@ -64,6 +64,8 @@ def load_library():
         "tfhe_keygen_cloud_seeded": [vp, u32p, u32p, C.c_double, C.c_double, C.POINTER(C.c_uint64)],
         "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
         "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
+        "tfhe_bootstrap_extended_batch": [vp, u32p, u32p, C.c_int, C.c_int, u32p, C.c_int],
+        "tfhe_bootstrap_extended_batch_dev": [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp],
         "tfhe_blind_rotate_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int, C.c_int],
         "tfhe_blind_rotate_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp],
         "tfhe_external_product_batch": [vp, C.c_int, u32p, u32p, C.c_int],
@@ -230,6 +232,20 @@ class Context:
         tv, per = self._tv(testvec, B)
         out = np.empty_like(cts)
         self._check(self._lib.tfhe_bootstrap_batch(self._h, _p32(cts), _p32(tv), per, _p32(out), B))
+        return out
+
+    def bootstrap_extended_batch(self, cts, lut):
+        """Programmable bootstrap through an extended lookup table: lut [ext][2][N] (shared) or [B][ext][2][N]."""
+        p = self.params
+        cts = _u32(cts)
+        B = cts.shape[0]
+        lut = _u32(lut)
+        per = 1 if lut.ndim == 4 else 0
+        ext = lut.shape[1] if per else lut.shape[0]
+        if lut.shape[-2:] != (2, p.N) or (per and lut.shape[0] != B):
+            raise ValueError("lut must be [ext][2][N] or [B][ext][2][N]")
+        out = np.empty((B, p.n + 1), np.uint32)
+        self._check(self._lib.tfhe_bootstrap_extended_batch(self._h, _p32(cts), _p32(lut), per, int(ext), _p32(out), B))
         return out
 
     def blind_rotate_batch(self, cts, testvec=None, nsteps=-1):

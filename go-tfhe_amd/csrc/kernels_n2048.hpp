@@ -148,8 +148,8 @@ __device__ __forceinline__ uint32_t diff_coeff_2048(const uint32_t *accL, int at
 }
 
 // One external product for L = 1 (evaluator.go:50-81): this wave's half of bsk[i] (x) d.
-template <int BGBIT>
-__device__ __forceinline__ void external_product_core_2048(const uint32_t *accL, int at, const uint32_t *plain,
+template <int BGBIT, class Coef>
+__device__ __forceinline__ void external_product_core_2048(Coef coef /* j -> coefficient j of the polynomial to decompose */,
                                                            uint32_t (&e)[32], const cd *__restrict__ key_ip,
                                                            cd *sc_mine, const cd *sc_other, const cd *__restrict__ table,
                                                            const LaneTwiddles2048 &tw, uint32_t offset, int p, int lane)
@@ -160,8 +160,8 @@ __device__ __forceinline__ void external_product_core_2048(const uint32_t *accL,
     cd x[16];
 #pragma unroll
     for (int a = 0; a < 16; a++) {
-        const uint32_t d0 = diff_coeff_2048(accL, at, plain, 64 * a + lane) + offset;
-        const uint32_t d1 = diff_coeff_2048(accL, at, plain, 64 * a + lane + 1024) + offset;
+        const uint32_t d0 = coef(64 * a + lane) + offset;
+        const uint32_t d1 = coef(64 * a + lane + 1024) + offset;
         x[a] = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
     }
     fft1024_forward(x, sc_mine, table, tw, lane);
@@ -332,10 +332,97 @@ __global__ __launch_bounds__(128) void k_external_product_2048(const cd *bsk, co
     const uint32_t *src = in + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
     uint32_t e[32];
     const cd *key = bsk + ((size_t)key_index * 2 + p) * 2 * 1024;
-    external_product_core_2048<BGBIT>(nullptr, 0, src, e, key, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
+    external_product_core_2048<BGBIT>([&](int j) { return src[j]; }, e, key, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
     uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 32; q++) dst[64 * q + lane] = e[q];
+}
+
+// ------------------------------------------------------------------------------------
+// Extended lookup tables (LookUpTableSize = ext * N > N; params.go:399-402,440-443,481-484: Uint6/7/8 carry the
+// parameters, the reference leaves the algorithm out -- params/UINT_STATUS.md:12-30).  The table is a polynomial
+// P(Y) of degree ext*N over Y^(ext*N) = -1, kept as ext ring elements p_k(X), X = Y^ext:
+// P(Y) = sum_k Y^k p_k(Y^ext).  Multiplying by Y^a, a = ext*q + r, sends component k to component (k + r) mod ext
+// rotated by X^q (X^(q+1) when k + r wrapped), so one CMUX step of the blind rotation is ext external products:
+//     acc_k <- acc_k + bsk[i] (x) ( X^(q + [k < r]) * acc_((k - r) mod ext) - acc_k ),   a = modswitch(ct[i]) in [0, 2 ext N).
+// ext = 1 is exactly evaluator.BlindRotateAssign (evaluator.go:110-135).  One launch per step over B * ext
+// (item, component) pairs, accumulators double-buffered in global memory [ext][B][2][N]: a functional path for the
+// experimental sets (launch-bound: ~n launches per batch), not a tuned one.
+// ------------------------------------------------------------------------------------
+struct ExtendedArgs {
+    const cd *bsk, *tw;
+    const uint32_t *in;        // [B][n+1] LWE samples
+    const uint32_t *lut;       // [ext][2][N] (shared) or [B][ext][2][N]
+    long lut_stride;           // 0 or ext*2*N
+    uint32_t *amod;            // [B][n+1]: every word mod-switched to [0, 2*ext*N); the body holds 2*ext*N - modswitch(b)
+    const uint32_t *acc_in;    // [ext][B][2][N]
+    uint32_t *acc_out;
+    int n, ext, B, step;
+    uint32_t offset;
+};
+
+// rotation amount and source component for target component k of Y^a * acc
+__device__ __forceinline__ void ext_rotation(int a, int ext, int k, int &src, int &s)
+{
+    const int q = a / ext, r = a - q * ext;
+    src = k - r; if (src < 0) src += ext;
+    s = q + (k < r ? 1 : 0);
+}
+__device__ __forceinline__ uint32_t rot_coeff_2048(const uint32_t *__restrict__ poly, int s, int j)
+{
+    const int t = (j - s) & 4095;                       // X^s * poly, X^2048 = -1; "negation" is the complement
+    return poly[t & 2047] ^ (0u - (uint32_t)((t >> 11) & 1));
+}
+
+// mod-switch of every word to the big ring and the initial accumulators acc_k = component k of Y^(b~) * LUT.
+static __global__ void k_ext_init_2048(ExtendedArgs A)
+{
+    constexpr int N = 2048;
+    const int item = blockIdx.x, n = A.n, ext = A.ext;
+    const uint32_t *ct = A.in + (size_t)item * (n + 1);
+    const unsigned long long big2 = 2ull * ext * N;
+    __shared__ int bt;
+    for (int x = threadIdx.x; x <= n; x += blockDim.x) {
+        // round(ct * 2*ext*N / 2^32): for ext a power of two this is (ct + rnd) >> sh of evaluator.go:116,122
+        unsigned int a = (unsigned int)(((unsigned long long)ct[x] * big2 + (1ull << 31)) >> 32);
+        if (a >= big2) a -= (unsigned int)big2;
+        if (x == n) { a = (unsigned int)((big2 - a) % big2); bt = (int)a; }
+        A.amod[(size_t)item * (n + 1) + x] = a;
+    }
+    __syncthreads();
+    const uint32_t *lut = A.lut + (size_t)item * A.lut_stride;
+    for (int k = 0; k < ext; k++) {
+        int src, s;
+        ext_rotation(bt, ext, k, src, s);
+        for (int part = 0; part < 2; part++) {
+            uint32_t *dst = A.acc_out + (((size_t)k * A.B + item) * 2 + part) * N;
+            const uint32_t *sp = lut + ((size_t)src * 2 + part) * N;
+            for (int j = threadIdx.x; j < N; j += blockDim.x) dst[j] = rot_coeff_2048(sp, s, j);
+        }
+    }
+}
+
+template <int BGBIT>
+__global__ __launch_bounds__(128) void k_cmux_ext_2048(ExtendedArgs A)
+{
+    constexpr int N = 2048;
+    __shared__ cd sc[2][kScratchSlots2048];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ext = A.ext, item = blockIdx.x / ext, k = blockIdx.x - item * ext;
+    LaneTwiddles2048 tw;
+    load_lane_twiddles_2048(tw, A.tw, lane);
+    int src, s;
+    ext_rotation((int)A.amod[(size_t)item * (A.n + 1) + A.step], ext, k, src, s);
+    const uint32_t *cur = A.acc_in + (((size_t)k * A.B + item) * 2 + p) * N;
+    const uint32_t *rot = A.acc_in + (((size_t)src * A.B + item) * 2 + p) * N;
+    uint32_t e[32];
+    const cd *key = A.bsk + ((size_t)A.step * 2 + p) * 2 * 1024;
+    external_product_core_2048<BGBIT>([&](int j) { return rot_coeff_2048(rot, s, j) - cur[j]; }, e, key, sc[p], sc[p ^ 1],
+                                      A.tw, tw, A.offset, p, lane);
+    uint32_t *dst = A.acc_out + (((size_t)k * A.B + item) * 2 + p) * N;
+#pragma unroll
+    for (int q = 0; q < 32; q++) dst[64 * q + lane] = cur[64 * q + lane] + e[q];
 }
 
 // Reference Fourier layout [n][2][2][2048] float64 -> device layout (L = 1).

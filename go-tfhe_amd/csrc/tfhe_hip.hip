@@ -450,6 +450,37 @@ int bootstrap_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, in
     return TFHE_OK;
 }
 
+// Programmable bootstrap through an extended lookup table (kernels_n2048.hpp: ExtendedArgs), N = 2048 shape only.
+int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_lut, int lut_per_item, int ext,
+                              uint32_t *d_out, int B, hipStream_t st)
+{
+    if (c->shape != kShapeN2048_L1_B22) return fail(TFHE_E_INVALID, "extended lookup tables need the N = 2048 parameter shape");
+    if (ext < 1 || ext > 16) return fail(TFHE_E_INVALID, "polyExtendFactor %d out of range (1..16)", ext);
+    const size_t N = 2048, n1 = (size_t)c->P.n + 1;
+    const size_t accw = (size_t)ext * B * 2 * N;
+    int rc;
+    if ((rc = c->s_t2.reserve(2 * accw * sizeof(uint32_t))) || (rc = c->s_t3.reserve((size_t)B * n1 * sizeof(uint32_t)))) return rc;
+    uint32_t *acc[2] = {c->s_t2.as<uint32_t>(), c->s_t2.as<uint32_t>() + accw};
+    ExtendedArgs a{};
+    a.bsk = c->bsk.as<cd>(); a.tw = c->tw.as<cd>();
+    a.in = d_in; a.lut = d_lut; a.lut_stride = lut_per_item ? (long)ext * 2 * N : 0;
+    a.amod = c->s_t3.as<uint32_t>();
+    a.n = c->P.n; a.ext = ext; a.B = B; a.offset = c->offset;
+    a.acc_out = acc[0];
+    hipEvent_t stop;
+    int trc = timing_begin(c, 0, st, &stop);
+    if (trc) return trc;
+    hipLaunchKernelGGL(k_ext_init_2048, dim3(B), dim3(256), 0, st, a);
+    for (int i = 0; i < c->P.n; i++) {
+        a.step = i; a.acc_in = acc[i & 1]; a.acc_out = acc[(i + 1) & 1];
+        hipLaunchKernelGGL((k_cmux_ext_2048<22>), dim3((unsigned)(B * ext)), dim3(128), 0, st, a);
+    }
+    HIP_TRY(hipGetLastError());
+    if ((rc = timing_end(c, 0, st, stop))) return rc;
+    // component 0 of the final accumulators is contiguous [B][2][N]: sample extract + key switch as usual
+    return launch_keyswitch(c, acc[c->P.n & 1], d_out, B, nullptr, st);
+}
+
 // Reads and clears the device status word (after the caller has synchronised the stream the work ran on).
 int check_status(tfhe_ctx *c)
 {
@@ -805,6 +836,16 @@ int tfhe_bootstrap_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *
     return bootstrap_device(c, d_in, d_tv, tv_per_item, d_out, B, st);
 }
 
+int tfhe_bootstrap_extended_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_lut, int lut_per_item, int ext,
+                                      uint32_t *d_out, int B, void *stream)
+{
+    DEV_PROLOGUE();
+    if (B < 0 || (B > 0 && (!d_in || !d_lut || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
+    if (B == 0) return TFHE_OK;
+    return bootstrap_extended_device(c, d_in, d_lut, lut_per_item, ext, d_out, B, st);
+}
+
 int tfhe_gate_batch_dev(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a, const uint32_t *d_b,
                         const uint32_t *d_c, uint32_t *d_out, int B, void *stream)
 {
@@ -872,6 +913,27 @@ int tfhe_bootstrap_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, in
     if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
     if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
                                c->s_out.as<uint32_t>(), B, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_bootstrap_extended_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *lut, int lut_per_item, int ext,
+                                  uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !lut || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (ext < 1 || ext > 16) return fail(TFHE_E_INVALID, "polyExtendFactor %d out of range (1..16)", ext);
+    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t inb = (size_t)B * (c->P.n + 1) * 4, lutb = (size_t)(lut_per_item ? B : 1) * ext * 2 * c->P.N * 4;
+    if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_out.reserve(inb)) || (rc = c->s_tv.reserve(lutb))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_tv.p, lut, lutb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = bootstrap_extended_device(c, c->s_in0.as<uint32_t>(), c->s_tv.as<uint32_t>(), lut_per_item, ext,
+                                        c->s_out.as<uint32_t>(), B, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;

@@ -46,6 +46,20 @@ class Evaluator:
     def BootstrapFuncAssign(self, ct_in, f, messageModulus, ct_out):
         ct_out[...] = self.BootstrapFunc(ct_in, f, messageModulus)
 
+    # Extended tables (LookUpTableSize = polyExtendFactor * N): what the Uint6/7/8 sets are specified for and the
+    # reference leaves out (params.go:399-402, params/UINT_STATUS.md:12-30).  lut: [ext][2][N] from
+    # lut.Generator(params, modulus, polyExtendFactor=ext).GenLookUpTableExtended(f).
+    def BootstrapLUTExtended(self, ct_in, lut):
+        return self.ctx.bootstrap_extended_batch(np.asarray(ct_in)[None], lut)[0]
+
+    def BootstrapFuncExtended(self, ct_in, f, messageModulus, polyExtendFactor):
+        from .lut import Generator
+        gen = Generator(self.ctx.params, messageModulus, polyExtendFactor=polyExtendFactor)
+        return self.BootstrapLUTExtended(ct_in, gen.GenLookUpTableExtended(f))
+
+    def BatchBootstrapLUTExtended(self, cts, lut):
+        return self.ctx.bootstrap_extended_batch(cts, lut)
+
     # one table, many ciphertexts in one launch (the batch form of BootstrapLUT)
     def BatchBootstrapLUT(self, cts, lut):
         return self.ctx.bootstrap_batch(cts, getattr(lut, "poly", lut))

@@ -77,11 +77,16 @@ class Encoder:
 
 
 class Generator:
-    """lut.Generator (generator.go:10-173) for one parameter set (ring degree N = LookUpTableSize;
-    the reference's extended tables, LookUpTableSize > N, are not implemented there either)."""
+    """lut.Generator (generator.go:10-173) for one parameter set.  The reference only builds tables with
+    LookUpTableSize = N (polyExtendFactor = 1, generator.go:19-20); polyExtendFactor > 1 gives the EXTENDED tables
+    its Uint6/7/8 parameter sets are specified for (params.go:399-402,440-443,481-484) and that it leaves
+    unimplemented: the same construction over LookUpTableSize = polyExtendFactor * N positions, handed to the
+    engine de-interleaved (GenLookUpTableExtended, tfhe_bootstrap_extended_batch)."""
 
-    def __init__(self, params, messageModulus, scale=None):
-        self.PolyDegree = self.LookUpTableSize = int(params.N)
+    def __init__(self, params, messageModulus, scale=None, polyExtendFactor=1):
+        self.PolyDegree = int(params.N)
+        self.PolyExtendFactor = int(polyExtendFactor)
+        self.LookUpTableSize = self.PolyDegree * self.PolyExtendFactor
         self.Encoder = Encoder(messageModulus, scale)
 
     def _layout(self, modulus):
@@ -95,11 +100,27 @@ class Generator:
         msg = np.searchsorted(bounds, src, side="right") - 1
         return msg, np.arange(N) >= N - offset
 
-    def _fill(self, values, modulus, out):
+    def _table(self, values, modulus):
         msg, neg = self._layout(modulus)
         b = np.asarray(values, np.uint32)[msg]
+        return np.where(neg, (0 - b.astype(np.int64)) & 0xFFFFFFFF, b).astype(np.uint32)
+
+    def _fill(self, values, modulus, out):
+        if self.PolyExtendFactor != 1:
+            raise ValueError("a LookUpTable holds N coefficients: use GenLookUpTableExtended for polyExtendFactor > 1")
         out.poly[0] = 0
-        out.poly[1] = np.where(neg, (0 - b.astype(np.int64)) & 0xFFFFFFFF, b).astype(np.uint32)
+        out.poly[1] = self._table(values, modulus)
+        return out
+
+    def GenLookUpTableExtended(self, f, full=False):
+        """The table of f over LookUpTableSize = ext * N positions as [ext][2][N] uint32: component k holds the
+        coefficients of Y^(i*ext + k) of the big polynomial (A parts zero), the layout tfhe_bootstrap_extended_batch
+        takes.  ext = 1 gives GenLookUpTable(f).poly[None].  full=True: f returns raw torus values."""
+        m, ext, N = self.Encoder.MessageModulus, self.PolyExtendFactor, self.PolyDegree
+        vals = [int(f(x)) & 0xFFFFFFFF for x in range(m)] if full else self.Encoder.Encode([int(f(x)) for x in range(m)])
+        big = self._table(vals, m)                         # [ext * N]
+        out = np.zeros((ext, 2, N), np.uint32)
+        out[:, 1, :] = big.reshape(N, ext).T
         return out
 
     def GenLookUpTable(self, f):

@@ -144,6 +144,20 @@ int tfhe_bootstrap_batch(tfhe_ctx *ctx, const uint32_t *in, const uint32_t *test
 int tfhe_bootstrap_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in, const uint32_t *d_testvec,
                              int testvec_per_item, uint32_t *d_out, int B, void *stream);
 
+/* Programmable bootstrap through an EXTENDED lookup table, LookUpTableSize = ext * N (polyExtendFactor = ext):
+ * what the Uint6 / Uint7 / Uint8 parameter sets are specified for (params.go:399-402,440-443,481-484) and the
+ * reference does not implement (params/UINT_STATUS.md:12-30, uint_params_test.go:29-31 skips them).  The table
+ * is a polynomial of degree ext*N over Y^(ext*N) = -1, handed over de-interleaved:
+ *   lut [ext][2][N]   component k holds the coefficients of Y^(i*ext + k), i < N (A then B); shared, or
+ *                     [B][ext][2][N] with lut_per_item = 1
+ * ext = 1 is tfhe_bootstrap_batch.  Every ciphertext word is mod-switched to [0, 2*ext*N) and each CMUX step
+ * runs ext external products (one launch per step: a functional path for the experimental sets).  N = 2048
+ * parameter shape only; anything else returns TFHE_E_INVALID. */
+int tfhe_bootstrap_extended_batch(tfhe_ctx *ctx, const uint32_t *in, const uint32_t *lut, int lut_per_item,
+                                  int ext, uint32_t *out, int B);
+int tfhe_bootstrap_extended_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in, const uint32_t *d_lut, int lut_per_item,
+                                      int ext, uint32_t *d_out, int B, void *stream);
+
 /* Evaluator.BlindRotateAssign / trgsw.BatchBlindRotate (evaluator.go:110-135,
  * trgsw.go:234-252): out_trlwe [B][2][N].  nsteps < 0 means all n CMUX steps; a
  * smaller value stops the chain early (test seam for CMuxAssign, evaluator.go:85-106). */

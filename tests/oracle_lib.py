@@ -151,6 +151,34 @@ class Oracle:
                                         C.c_int(nsteps), _u32p(out))
         return out
 
+    def blind_rotate_extended(self, p, bsk, ct, lut, nsteps=-1):
+        """Blind rotation through an extended lookup table lut [ext][2][N] (LookUpTableSize = ext*N), composed from the
+        restated primitives: acc_k <- CMux(bsk[i], acc_k, X^(q + [k<r]) acc_((k-r) mod ext)) with a = ext*q + r the
+        mod-switch of ct[i] to [0, 2 ext N).  ext = 1 is BlindRotateAssign (evaluator.go:110-135).  Returns [ext][2][N]."""
+        ext, N = lut.shape[0], p.N
+        big2 = 2 * ext * N
+        ms = lambda x: ((int(x) * big2 + (1 << 31)) >> 32) % big2
+
+        def rotate(acc, a):
+            q, r = divmod(a, ext)
+            out = np.empty_like(acc)
+            for k in range(ext):
+                src, s = (k - r) % ext, q + (1 if k < r else 0)
+                for part in range(2):
+                    out[k, part] = self.poly_mul_xk(np.ascontiguousarray(acc[src, part]), s)
+            return out
+
+        acc = rotate(np.ascontiguousarray(lut, np.uint32), (big2 - ms(ct[p.n])) % big2)
+        steps = p.n if nsteps < 0 else nsteps
+        for i in range(steps):
+            rot = rotate(acc, ms(ct[i]))
+            acc = np.stack([self.cmux(p, bsk[i], np.ascontiguousarray(acc[k]), np.ascontiguousarray(rot[k])) for k in range(ext)])
+        return acc
+
+    def bootstrap_extended(self, p, bsk, ksk, ct, lut):
+        acc = self.blind_rotate_extended(p, bsk, ct, lut)
+        return self.key_switch(p, ksk, self.sample_extract(np.ascontiguousarray(acc[0])))
+
     def sample_extract(self, trlwe, k=0):
         N = trlwe.shape[-1]
         out = np.empty(N + 1, np.uint32)

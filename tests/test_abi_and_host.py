@@ -183,3 +183,36 @@ def test_cgo_shim_in_integration_md_matches_the_header():
         assert n == decl[name], f"{name}: shim passes {n} arguments, header declares {decl[name]}"
         calls += 1
     assert calls >= 9
+
+
+def test_extended_lut_generator(pkg, oracle):
+    # Extended tables (LookUpTableSize = ext * N; params.go:399-402): ext = 1 is the reference's table; for ext > 1 the
+    # de-interleaved components re-assemble to the same construction over ext*N positions, and multiplying the big
+    # polynomial by Y^a is "component (k - r) mod ext rotated by q + [k < r]" (what the engine's kernels do).
+    from go_tfhe_amd.lut import Generator
+    p = pkg.params.SecurityUint5
+    f = lambda x: (3 * x + 1) % 64
+    g1 = Generator(p, 32)
+    assert np.array_equal(g1.GenLookUpTableExtended(lambda x: x % 32)[0], g1.GenLookUpTable(lambda x: x % 32).poly)
+    for ext in (2, 4, 9):
+        g = Generator(p, 64, polyExtendFactor=ext)
+        t = g.GenLookUpTableExtended(f)
+        assert t.shape == (ext, 2, p.N) and not t[:, 0].any()
+        big = t[:, 1, :].T.reshape(-1)                       # big[i*ext + k] = component k, coefficient i
+        S = ext * p.N
+        box, off = S // 64, S // 128
+        enc = g.Encoder.Encode([f(x) for x in range(64)])
+        want = np.array([enc[((i + off) % S) // box] for i in range(S)], np.uint32)
+        want[S - off:] = (0 - want[S - off:].astype(np.int64)) & 0xFFFFFFFF
+        assert np.array_equal(big, want), ext
+        rs = np.random.RandomState(ext)
+        P = rs.randint(0, 2**32, size=S, dtype=np.uint64).astype(np.uint32)
+        comp = P.reshape(p.N, ext).T
+        for a in (0, 1, ext - 1, ext, 5 * ext + 2, S - 1, S, 2 * S - 3):
+            # big-ring rotation with the reference's "negation" (bitwise complement, buffer_methods.go:133-164)
+            idx = (np.arange(S) - a) % (2 * S)
+            bigrot = np.where(idx < S, P[idx % S], ~P[idx % S])
+            q, r = divmod(a, ext)
+            for k in range(ext):
+                got = oracle.poly_mul_xk(np.ascontiguousarray(comp[(k - r) % ext]), q + (1 if k < r else 0))
+                assert np.array_equal(got, bigrot.reshape(p.N, ext).T[k]), (ext, a, k)
