@@ -135,6 +135,18 @@ def cpu_baseline(key, a, b, budget_s=12.0):
             "single_thread_ms_per_gate": one * 1e3}
 
 
+def emit(line):
+    """The JSON line, as the LAST thing on stdout: RCCL printf()s a version banner into the C stdio buffer when a
+    communicator is created, which would otherwise be flushed behind it at process exit."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,10 +293,11 @@ def main():
             line["key_broadcast_ms"] = key_broadcast_ms
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(key, a_h, b_h)
-        print(json.dumps(line), flush=True)
     ck.close()
     if dist:
         dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 def sharded_mode(args, pkg, p, key, ck, dist, backend, rank, world, dev):
@@ -375,9 +388,10 @@ def sharded_mode(args, pkg, p, key, ck, dist, backend, rank, world, dev):
                 "scatter_ms_per_step": float(tt[1]) * 1e3 / args.steps, "compute_ms_per_step": float(tt[2]) * 1e3 / args.steps,
                 "gather_ms_per_step": float(tt[3]) * 1e3 / args.steps, "scaling": "strong", "verified": all(checks.values()),
                 "checks": checks, **extra}
-        print(json.dumps(line), flush=True)
     ck.close()
     dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 if __name__ == "__main__":
