@@ -44,6 +44,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise TfheError(-3, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(the HIP extension is required; there is no CPU fallback)")
+    # One HIP runtime per process: torch ships its own libamdhip64, the library links the system one.  Whichever is
+    # loaded first serves both -- but only torch-first works (loading torch after the system runtime leaves it with
+    # "No HIP GPUs are available"), and the device-pointer entry points exist to be fed torch tensors.  So torch, when
+    # installed, is imported before the library is opened; the host-pointer API needs neither torch nor this.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     u32p, u8p, f64p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_void_p
     lib.tfhe_last_error.restype = C.c_char_p

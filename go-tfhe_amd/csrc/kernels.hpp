@@ -2,10 +2,14 @@
 //
 //   k_blind_rotate        evaluator.BlindRotateAssign (evaluator.go:110-135) with the gate's
 //                         linear preparation (gates_helper.go:10-63) and the mod-switch fused
-//                         into its prologue.  One workgroup = one bootstrap, two wavefronts:
-//                         wave 0 owns accumulator polynomial A, wave 1 owns B.  The n CMUX
-//                         steps run inside the kernel with the accumulator resident in LDS;
-//                         only the bootstrapping key is streamed.
+//                         into its prologue.  One bootstrap = two wavefronts (wave 0 owns accumulator
+//                         polynomial A, wave 1 owns B), 1, 2 or 4 bootstraps per workgroup by launch
+//                         size.  The n CMUX steps run inside the kernel with the accumulator resident
+//                         in LDS; only the bootstrapping key is streamed.  (Launches of up to one
+//                         workgroup per CU use the four-wave form, kernels_quad.hpp; N = 2048 and
+//                         N = 512 rings have their own files.)
+//   gate_prep_modswitch   the prologue all blind-rotate kernels share, incl. the list indirection of the
+//                         device-side MUX split;  k_mux_count / _scan / _fill / _all build that list.
 //   k_external_product    evaluator.ExternalProductAssign (evaluator.go:50-81), same core.
 //   k_extract_keyswitch   trlwe.SampleExtractIndexAssign + trgsw.IdentityKeySwitchingAssign
 //                         (trlwe_ops.go:10-21, keyswitch.go:10-37), per-ciphertext gather (small batches);

@@ -93,6 +93,29 @@ def test_keygen_rejects_bad_input(pkg):
     ctx.close()
 
 
+def test_default_seed_is_os_entropy(oracle, pkg):
+    # CloudKey.NewCloudKey(seed=None) -> tfhe_keygen_cloud_seeded(..., NULL): 128 bits from getrandom per call, like the
+    # reference's auto-seeded generator (key/key.go:17).  Two keys from the same secret key differ (their blobs share
+    # essentially no words), both evaluate gates correctly; a fixed 128-bit seed is reproducible and differs from the
+    # 64-bit seed with the same low word.
+    p = oracle.params("128").small(12)
+    rng = oracle.rng(0x7F4E0045)
+    s0, s1 = oracle.keygen_secret(p, rng)
+    A, B = [0, 0, 1, 1], [0, 1, 0, 1]
+    a, b = oracle.encrypt_bools(p, rng, A, s0), oracle.encrypt_bools(p, rng, B, s0)
+    blobs = []
+    for seed in (None, None, (5 << 64) | 9, (5 << 64) | 9, 9):
+        ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=seed)
+        assert list(oracle.decrypt_bools(p, s0, ck.ctx.gate_batch("NAND", a, b))) == [True, True, True, False]
+        blobs.append(ck.ctx.key_export_dev(0).cpu().numpy().view(np.uint32).copy())   # the bootstrapping key (no padding words)
+        ck.close()
+    assert (blobs[0] == blobs[1]).mean() < 0.01                   # OS entropy: unrelated keys
+    assert np.array_equal(blobs[2], blobs[3])                     # fixed seed: reproducible
+    assert (blobs[2] == blobs[4]).mean() < 0.01                   # the high 64 bits of the seed matter
+    with pytest.raises(ValueError):
+        pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=1 << 128)
+
+
 def _wave_blob_to_reference_spectra(blob, n, L):
     """Device layout cd bsk[n][2][L][2][8][64] (csrc/kernels.hpp) -> reference FourierPoly layout [n][2L][2][1024]:
     (reg, lane) holds root u = (lane>>3) + 8*(lane&7) + 64*reg, the reference keeps it in slot bitrev9(-u mod 512),
