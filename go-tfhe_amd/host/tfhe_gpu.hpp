@@ -177,13 +177,29 @@ struct Encoder {
     bool DecodeBool(params::Torus v) const { return Decode(v) != 0; }
 };
 
-// generator.go:10-173 for one parameter set (LookUpTableSize = N; the reference has no extended tables either)
+// generator.go:10-173 for one parameter set.  polyExtendFactor > 1 gives the EXTENDED tables the Uint6/7/8 sets are
+// specified for (LookUpTableSize = polyExtendFactor * N, params.go:399-402,440-443,481-484) and the reference does not
+// implement (generator.go:19-20): GenLookUpTableExtended + Evaluator::BootstrapLUTExtended.
 class Generator {
   public:
     Encoder Enc;
-    int PolyDegree, LookUpTableSize;
-    Generator(const params::Params &p, int messageModulus) : Enc(messageModulus), PolyDegree(p.N), LookUpTableSize(p.N) {}
-    Generator(const params::Params &p, int messageModulus, double scale) : Enc(messageModulus, scale), PolyDegree(p.N), LookUpTableSize(p.N) {}
+    int PolyDegree, PolyExtendFactor, LookUpTableSize;
+    Generator(const params::Params &p, int messageModulus, int polyExtendFactor = 1)
+        : Enc(messageModulus), PolyDegree(p.N), PolyExtendFactor(polyExtendFactor), LookUpTableSize(p.N * polyExtendFactor) {}
+    Generator(const params::Params &p, int messageModulus, double scale)
+        : Enc(messageModulus, scale), PolyDegree(p.N), PolyExtendFactor(1), LookUpTableSize(p.N) {}
+
+    // The table of f over LookUpTableSize positions, de-interleaved: [ext][2][N] uint32, component k = coefficients of
+    // Y^(i*ext + k) of the big polynomial (A parts zero) -- the layout tfhe_bootstrap_extended_batch takes.
+    std::vector<params::Torus> GenLookUpTableExtended(const std::function<int(int)> &f) const
+    {
+        const std::vector<params::Torus> big = table(Enc.MessageModulus, [&](int x) { return Enc.Encode(f(x)); });
+        const size_t N = (size_t)PolyDegree, ext = (size_t)PolyExtendFactor;
+        std::vector<params::Torus> out(ext * 2 * N, 0u);
+        for (size_t i = 0; i < N; i++)
+            for (size_t k = 0; k < ext; k++) out[(k * 2 + 1) * N + i] = big[i * ext + k];
+        return out;
+    }
 
     LookUpTable GenLookUpTable(const std::function<int(int)> &f) const
     {
@@ -207,20 +223,26 @@ class Generator {
     static long divRound(long a, long b) { return (a + b / 2) / b; }       // generator.go:171-173
     // Coefficient i of the table is the value of the message whose raw range contains (i + offset) mod N,
     // offset = divRound(N, 2m); the coefficients that wrapped around are negated  (generator.go:62-93).
-    LookUpTable fill(int m, const std::function<params::Torus(int)> &value) const
+    std::vector<params::Torus> table(int m, const std::function<params::Torus(int)> &value) const
     {
         const long N = LookUpTableSize, offset = divRound(N, 2L * m);
-        std::vector<params::Torus> val((size_t)m);
+        std::vector<params::Torus> val((size_t)m), out((size_t)N);
         for (int x = 0; x < m; x++) val[(size_t)x] = value(x);
-        LookUpTable out((int)N);
         int x = 0;
         for (long k = 0; k < N; k++) {                           // k walks the raw positions, in rotated order
             const long src = (k + offset) % N;
             if (src == 0) x = 0;
             while (x + 1 < m && src >= divRound((long)(x + 1) * N, m)) x++;
             const params::Torus v = val[(size_t)x];
-            out.Poly.B[(size_t)k] = k >= N - offset ? 0u - v : v;
+            out[(size_t)k] = k >= N - offset ? 0u - v : v;
         }
+        return out;
+    }
+    LookUpTable fill(int m, const std::function<params::Torus(int)> &value) const
+    {
+        if (PolyExtendFactor != 1) throw Panic(TFHE_E_INVALID, "a LookUpTable holds N coefficients: use GenLookUpTableExtended");
+        LookUpTable out(PolyDegree);
+        out.Poly.B = table(m, value);
         return out;
     }
 };
@@ -281,6 +303,16 @@ class Evaluator {
     void BootstrapFuncAssign(const tlwe::TLWELv0 &ctIn, const std::function<int(int)> &f, int messageModulus, tlwe::TLWELv0 &ctOut) const
     {
         ctOut = BootstrapFunc(ctIn, f, messageModulus);
+    }
+    // extended tables: lut = Generator(P, m, ext).GenLookUpTableExtended(f), [ext][2][N]
+    tlwe::TLWELv0 BootstrapLUTExtended(const tlwe::TLWELv0 &ctIn, const std::vector<params::Torus> &lut) const
+    {
+        const size_t per = 2 * (size_t)ck_.P.N;
+        if (lut.empty() || lut.size() % per) throw Panic(TFHE_E_INVALID, "extended table must be [ext][2][N]");
+        tlwe::TLWELv0 out;
+        out.P.resize(n1_);
+        check(tfhe_bootstrap_extended_batch(ck_.ctx(), ctIn.P.data(), lut.data(), 0, (int)(lut.size() / per), out.P.data(), 1));
+        return out;
     }
     // batch forms (trgsw.go:234-252)
     std::vector<tlwe::TLWELv0> BatchBootstrap(const std::vector<tlwe::TLWELv0> &in, const trlwe::TRLWELv1 *testvec = nullptr) const

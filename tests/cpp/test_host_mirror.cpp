@@ -126,6 +126,31 @@ int main()
                 EXPECT(out.P == wantf, "BootstrapFunc differs from the oracle (m=%d)", m);
             }
     }
+    // extended tables (polyExtendFactor > 1) need the N = 2048 shape: a Uint5-ring context with a short LWE dimension,
+    // key generated on the GPU from OS entropy (seed128 = nullptr); Uint6 = modulus 64 over a 4096-entry table
+    {
+        orc_params o5;
+        orc_get_params(3, &o5);
+        o5.n = 24;
+        params::Params p5{o5.n, o5.N, o5.Nbit, o5.L, o5.Bgbit, o5.basebit, o5.t};
+        std::vector<uint32_t> k0(o5.n), k1(o5.N);
+        orc_keygen_secret(&o5, &rng, k0.data(), k1.data());
+        auto ck5 = cloudkey::CloudKey::NewCloudKey(p5, k0, k1, o5.alpha_lv0, o5.alpha_lv1);
+        evaluator::Evaluator ev5(*ck5);
+        lut::Generator g6(p5, 64, 2);
+        EXPECT(g6.LookUpTableSize == 4096, "extended generator size");
+        const auto t6 = g6.GenLookUpTableExtended([](int x) { return 63 - x; });
+        EXPECT(t6.size() == (size_t)2 * 2 * 2048, "extended table shape");
+        for (int m : {0, 1, 31, 32, 62, 63}) {
+            gates::Ciphertext ct(o5.n);
+            orc_tlwe_encrypt_message(&o5, &rng, m, 64, k0.data(), ct.P.data());
+            auto out = ev5.BootstrapLUTExtended(ct, t6);
+            EXPECT(orc_tlwe_decrypt_message(&o5, 64, k0.data(), out.P.data()) == 63 - m, "BootstrapLUTExtended decrypts wrong (m=%d)", m);
+        }
+        bool threw6 = false;
+        try { g6.GenLookUpTable([](int x) { return x; }); } catch (const Panic &) { threw6 = true; }
+        EXPECT(threw6, "an extended generator must refuse to build an N-coefficient table");
+    }
     // error behaviour: a Go panic is a thrown Panic
     bool threw = false;
     try { gates::Ciphertext bad(3); gates::NAND(bad, bad, ck); } catch (const Panic &) { threw = true; }
