@@ -82,6 +82,9 @@ struct tfhe_ctx {
     uint32_t offset = 0;        // cloudkey.go:60-71
     int n1p = 0;                // padded LWE row length of the packed KSK
     int num_cus = 256;          // hipDeviceProp_t.multiProcessorCount
+    // host-pointer batches longer than one slab: transfers of slab s+1 / s-1 overlap the kernels of slab s
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    hipEvent_t pipe_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};      // [in, done, out][buffer]
     hipStream_t last_dev_stream = nullptr;      // stream of the most recent _dev call (tfhe_ctx_sync waits for it too)
     bool last_dev_stream_set = false;
     int quad_limit = 0;         // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
@@ -481,6 +484,60 @@ int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t 
     return launch_keyswitch(c, acc[c->P.n & 1], d_out, B, nullptr, st);
 }
 
+// Host-pointer gate batch longer than one slab (16,384 bootstraps at N = 1024): the operands of slab s+1 go up and
+// the results of slab s-1 come down on their own streams while the kernels of slab s run, through double-buffered
+// staging of one slab each -- a Go caller can only hand over host memory, so for it this IS the throughput path.
+int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b,
+                         const uint32_t *cc, uint32_t *out, int B)
+{
+    const int S = slab_items(c);
+    const size_t n1 = (size_t)c->P.n + 1, slab_rows = (size_t)S * n1 * 4;
+    int rc;
+    if ((rc = c->s_in0.reserve(2 * slab_rows)) || (rc = c->s_in1.reserve(2 * slab_rows)) || (rc = c->s_out.reserve(2 * slab_rows))) return rc;
+    if (cc && (rc = c->s_in2.reserve(2 * slab_rows))) return rc;
+    if (ops && (rc = c->s_ops.reserve(2 * (size_t)S))) return rc;
+    if ((rc = reserve_scratch(c, S, cc && (ops || op_uniform == TFHE_OP_MUX)))) return rc;
+    if (!c->h2d_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+        for (auto &pr : c->pipe_ev)
+            for (auto &e : pr) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));                    // earlier work of this context is done with the buffers
+    const int ns = (B + S - 1) / S;
+    auto dev = [&](DevBuf &d, int buf, size_t unit) { return static_cast<char *>(d.p) + (size_t)buf * unit; };
+    for (int s = 0; s <= ns; s++) {
+        const int buf = s & 1;
+        if (s < ns) {
+            const size_t base = (size_t)s * S, cnt = (size_t)(B - (int)base < S ? B - (int)base : S), bytes = cnt * n1 * 4;
+            if (s >= 2) HIP_TRY(hipStreamWaitEvent(c->h2d_stream, c->pipe_ev[1][buf], 0));      // slab s-2's kernels have read this buffer
+            HIP_TRY(hipMemcpyAsync(dev(c->s_in0, buf, slab_rows), a + base * n1, bytes, hipMemcpyHostToDevice, c->h2d_stream));
+            HIP_TRY(hipMemcpyAsync(dev(c->s_in1, buf, slab_rows), b + base * n1, bytes, hipMemcpyHostToDevice, c->h2d_stream));
+            if (cc) HIP_TRY(hipMemcpyAsync(dev(c->s_in2, buf, slab_rows), cc + base * n1, bytes, hipMemcpyHostToDevice, c->h2d_stream));
+            if (ops) HIP_TRY(hipMemcpyAsync(dev(c->s_ops, buf, (size_t)S), ops + base, cnt, hipMemcpyHostToDevice, c->h2d_stream));
+            HIP_TRY(hipEventRecord(c->pipe_ev[0][buf], c->h2d_stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_ev[0][buf], 0));
+            if (s >= 2) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_ev[2][buf], 0));           // slab s-2's results have left this buffer
+            if ((rc = gate_batch_device(c, ops ? reinterpret_cast<const uint8_t *>(dev(c->s_ops, buf, (size_t)S)) : nullptr, op_uniform,
+                                        reinterpret_cast<const uint32_t *>(dev(c->s_in0, buf, slab_rows)),
+                                        reinterpret_cast<const uint32_t *>(dev(c->s_in1, buf, slab_rows)),
+                                        cc ? reinterpret_cast<const uint32_t *>(dev(c->s_in2, buf, slab_rows)) : nullptr,
+                                        reinterpret_cast<uint32_t *>(dev(c->s_out, buf, slab_rows)), (int)cnt, c->stream))) return rc;
+            HIP_TRY(hipEventRecord(c->pipe_ev[1][buf], c->stream));
+        }
+        if (s >= 1) {                                            // results of slab s-1 (issued after slab s's uploads, so the
+            const int pb = (s - 1) & 1;                          // host blocks on them while slab s computes)
+            const size_t base = (size_t)(s - 1) * S, cnt = (size_t)(B - (int)base < S ? B - (int)base : S);
+            HIP_TRY(hipStreamWaitEvent(c->d2h_stream, c->pipe_ev[1][pb], 0));
+            HIP_TRY(hipMemcpyAsync(out + base * n1, dev(c->s_out, pb, slab_rows), cnt * n1 * 4, hipMemcpyDeviceToHost, c->d2h_stream));
+            HIP_TRY(hipEventRecord(c->pipe_ev[2][pb], c->d2h_stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
 // Reads and clears the device status word (after the caller has synchronised the stream the work ran on).
 int check_status(tfhe_ctx *c)
 {
@@ -580,6 +637,9 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     for (auto &v : c->tev)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto &pr : c->pipe_ev)
+        for (auto &e : pr) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {c->h2d_stream, c->d2h_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TFHE_OK;
@@ -954,6 +1014,7 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
         }
     }
     std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (B > slab_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
     if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_in1.reserve(rows)) || (rc = c->s_out.reserve(rows))) return rc;
     if (cc && (rc = c->s_in2.reserve(rows))) return rc;

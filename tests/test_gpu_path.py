@@ -367,6 +367,30 @@ def test_committed_golden_vectors_on_gpu(pkg, oracle):
         ck.close()
 
 
+def test_host_pointer_batches_longer_than_a_slab(oracle, keys_small, ck_small, pkg):
+    # tfhe_gate_batch on more than one slab (16,384 bootstraps) moves slab s+1's operands up and slab s-1's results down
+    # while slab s computes (double-buffered staging, three streams).  Same words as the same items issued in pieces that
+    # each fit one slab (the un-pipelined path), with per-item ops incl. MUX, a ragged last slab, and twice in a row
+    # (buffer reuse across calls).
+    k = keys_small
+    B = 2 * 16384 + 37
+    rs = np.random.RandomState(91)
+    a, b, c = (rand_u32(rs, (B, k.p.n + 1)) for _ in range(3))
+    ops = np.array([pkg.OPS[x] for x in ("NAND", "XOR", "MUX", "OR")], np.uint8)[rs.randint(0, 4, B)]
+    whole = ck_small.ctx.gate_batch(ops, a, b, c)
+    pieces = np.concatenate([ck_small.ctx.gate_batch(ops[i:i + 9000], a[i:i + 9000], b[i:i + 9000], c[i:i + 9000])
+                             for i in range(0, B, 9000)])
+    assert np.array_equal(whole, pieces)
+    assert np.array_equal(ck_small.ctx.gate_batch(ops, a, b, c), whole)
+    sample = [0, 16383, 16384, 32767, 32768, B - 1]
+    ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops[sample], np.ascontiguousarray(a[sample]), np.ascontiguousarray(b[sample]),
+                               np.ascontiguousarray(c[sample]))
+    assert np.array_equal(whole[sample], ref)
+    uni = ck_small.ctx.gate_batch("NAND", a, b)
+    sel = np.where(ops == pkg.OPS["NAND"])[0]
+    assert np.array_equal(uni[sel], whole[sel])
+
+
 def test_concurrent_host_threads(oracle, keys_small, ck_small, pkg):
     # A Go shim calls from many goroutines (the reference fans batches out over goroutines, trgsw.go:234-252).
     # ctypes drops the GIL, so these threads really overlap: four on one shared context (serialised by its
