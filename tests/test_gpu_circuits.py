@@ -148,6 +148,43 @@ def test_mixed_stream_4096_128bit(oracle, keys128, ck128, pkg):
     assert np.array_equal(om.cpu().numpy().view(np.uint32), ck128.ctx.gate_batch("MUX", a[:64], b[:64], c[:64]))
 
 
+def test_mux_stream_captured_into_a_graph(oracle, keys128, ck128, pkg):
+    # A per-item-op batch with MUX items is enqueue-only too (the split happens on the device), so it records into a HIP
+    # graph after tfhe_ctx_reserve has sized the intermediate buffers; replays on NEW operand values and a different MUX
+    # pattern in the same device buffers give what the eager call gives.
+    k = keys128
+    B = 700
+    rs = np.random.RandomState(61)
+    n1 = k.p.n + 1
+    bufs = [torch.empty((B, n1), dtype=torch.int32, device="cuda") for _ in range(4)]
+    ops_d = torch.empty(B, dtype=torch.uint8, device="cuda")
+
+    def fill():
+        a, b, c = (rand_u32(rs, (B, n1)) for _ in range(3))
+        ops = np.array([pkg.OPS[x] for x in ("AND", "MUX", "XNOR")], np.uint8)[rs.randint(0, 3, B)]
+        for t, v in zip(bufs[:3], (a, b, c)):
+            t.copy_(torch.from_numpy(v.view(np.int32)))
+        ops_d.copy_(torch.from_numpy(ops))
+        return ops, a, b, c
+
+    ck128.ctx.reserve(B, with_mux=True)
+    fill()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        ck128.ctx.gate_batch_dev(ops_d, bufs[0], bufs[1], bufs[2], bufs[3], side)       # warm-up on the capture stream
+    side.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        ck128.ctx.gate_batch_dev(ops_d, bufs[0], bufs[1], bufs[2], bufs[3], torch.cuda.current_stream())
+    for _ in range(2):
+        ops, a, b, c = fill()
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(bufs[3].cpu().numpy().view(np.uint32), ck128.ctx.gate_batch(ops, a, b, c))
+    ck128.ctx.sync()
+
+
 def test_dev_path_reports_bad_op_codes_at_sync(ck128, keys128, pkg):
     # tfhe_gate_batch_dev never copies the op codes back, so it cannot refuse them up front: the kernels record
     # the problem and tfhe_ctx_sync reports it once.  The host-pointer call still validates before issuing work.
