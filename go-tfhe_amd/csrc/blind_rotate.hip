@@ -18,7 +18,11 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
     // N=512: one wave and 16 KB LDS per bootstrap, 2 waves per SIMD -> 8 per CU.
     // N = 1024, launches of up to quad_max items: four waves per bootstrap (kernels_quad.hpp)
     const int quad_max = a0.bskq ? quad_limit : 0;
+#ifdef OCC3
+    const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 6 : 2) * num_cus;      // six 2-wave workgroups per CU
+#else
     const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 4 : 2) * num_cus;
+#endif
     for (int base = 0; base < B; base += cap) {
         const int cnt = B - base < cap ? B - base : cap;
         BlindRotateArgs a = a0;
@@ -42,6 +46,9 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
             }
             continue;
         }
+#ifdef OCC3
+        if (shape == kShapeN1024_L3_B6 && cnt > num_cus) { hipLaunchKernelGGL((k_blind_rotate<3, 6>), g, dim3(128), 0, st, a); continue; }
+#endif
         // Several items per workgroup (they share only the barriers), measured A/B on one box:
         //   769..1024 items: FOUR per 8-wave workgroup = every resident wave of a CU in one workgroup, in step on
         //                    the key stream: 6.84 (one item) -> 6.66 (two) -> 6.38 ms (four) at 1024;

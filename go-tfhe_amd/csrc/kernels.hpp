@@ -304,8 +304,15 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 // workgroup on distinct SIMDs but not those of two co-resident 2-wave workgroups (tools/ubench_placement.hip:
 // two workgroups per CU land as [2 0 1 1] waves per SIMD, one SIMD idle), so launches of 1..2 workgroups per
 // CU use this form: one 4-wave workgroup per CU = [1 1 1 1].  The two items only share the barriers.
+// -DOCC3 (with -DFFT_UNPADDED): the occupancy experiment of DESIGN.md -- one bootstrap per 2-wave workgroup at 27,140 B of
+// LDS (6 workgroups per CU) and a register budget of 168 (3 waves per SIMD); the compiler spills what does not fit.
+#ifdef OCC3
+#define BR_MIN_WAVES(items) ((items) == 1 ? 3 : 2)
+#else
+#define BR_MIN_WAVES(items) 2
+#endif
 template <int L, int BGBIT, int ITEMS = 1>
-__global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs A)
+__global__ __launch_bounds__(128 * ITEMS, BR_MIN_WAVES(ITEMS)) void k_blind_rotate(BlindRotateArgs A)
 {
     constexpr int N = 1024;
     __shared__ cd scAll[ITEMS][2][kScratchSlots];

@@ -73,39 +73,39 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
         dft8<1>(y0);
         TFHE_PRIO(3);
 #pragma unroll
-        for (int m = 0; m < 8; m++) sc[72 * m + lane] = y0[m];
+        for (int m = 0; m < 8; m++) sc[SL1W(m)] = y0[m];
         wave_lds_order();
 #pragma unroll
-        for (int b = 0; b < 8; b++) y0[b] = sc[72 * hi + 8 * b + lo];
+        for (int b = 0; b < 8; b++) y0[b] = sc[SL1R(b)];
         wave_lds_order();
         TFHE_PRIO(0);
         dft8<1>(y1);
         TFHE_PRIO(3);
 #pragma unroll
-        for (int m = 0; m < 8; m++) sc[72 * m + lane] = y1[m];
+        for (int m = 0; m < 8; m++) sc[SL1W(m)] = y1[m];
         wave_lds_order();
 #pragma unroll
-        for (int b = 0; b < 8; b++) y1[b] = sc[72 * hi + 8 * b + lo];
+        for (int b = 0; b < 8; b++) y1[b] = sc[SL1R(b)];
         wave_lds_order();
         TFHE_PRIO(0);
         twist_pow<false>(y0, tw.h[0].l2);
         dft8<1>(y0);
         TFHE_PRIO(3);
 #pragma unroll
-        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = y0[mp];
+        for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = y0[mp];
         wave_lds_order();
 #pragma unroll
-        for (int c = 0; c < 8; c++) y0[c] = sc[72 * hi + 9 * lo + c];
+        for (int c = 0; c < 8; c++) y0[c] = sc[SL2R(c)];
         wave_lds_order();
         TFHE_PRIO(0);
         twist_pow<false>(y1, tw.h[1].l2);
         dft8<1>(y1);
         TFHE_PRIO(3);
 #pragma unroll
-        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = y1[mp];
+        for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = y1[mp];
         wave_lds_order();
 #pragma unroll
-        for (int c = 0; c < 8; c++) y1[c] = sc[72 * hi + 9 * lo + c];
+        for (int c = 0; c < 8; c++) y1[c] = sc[SL2R(c)];
         wave_lds_order();
         TFHE_PRIO(0);
         twist_pow<false>(y0, tw.h[0].l3);

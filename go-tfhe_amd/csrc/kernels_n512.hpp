@@ -32,7 +32,7 @@ constexpr int kTwCount512 = 16 + 256 + 256;
 // per-half exchange scratch: 8 rows of 36 slots (32 used + 4 pad: row stride = 4 mod 16 keeps the
 // 16-lane ds_read_b128 service groups on distinct banks); two halves = kScratchSlots
 constexpr int kHalfScratch = 8 * 36;
-static_assert(2 * kHalfScratch == kScratchSlots, "half-wave scratch must tile the wave scratch");
+constexpr int kScratchSlots512 = 2 * kHalfScratch;      // (= the padded kScratchSlots of negacyclic_fft.hpp)
 
 struct LaneTwiddles512 {
     TwPow l2;        // level 2: w, w^2, w^4
@@ -205,7 +205,7 @@ template <int BGBIT>
 __global__ __launch_bounds__(64, 2) void k_blind_rotate_512(BlindRotateArgs A)
 {
     constexpr int N = 512;
-    __shared__ cd sc[kScratchSlots];
+    __shared__ cd sc[kScratchSlots512];
     __shared__ uint32_t accL[2][N];
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64) void k_external_product_512(const cd *__restric
                                                              uint32_t *__restrict__ out, uint32_t offset)
 {
     constexpr int N = 512;
-    __shared__ cd sc[kScratchSlots];
+    __shared__ cd sc[kScratchSlots512];
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
     LaneTwiddles512 tw;
     load_lane_twiddles_512(tw, twt, hl);
@@ -295,7 +295,7 @@ static __global__ void k_bsk_from_fourier_512(const double *__restrict__ src, cd
 static __global__ __launch_bounds__(64) void k_spectra_512(const uint32_t *__restrict__ src, cd *__restrict__ dst,
                                                            const cd *__restrict__ twt, int count)
 {
-    __shared__ cd sc[kScratchSlots];
+    __shared__ cd sc[kScratchSlots512];
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
     const int polyIdx = 2 * blockIdx.x + h;
     const bool live = polyIdx < count;
@@ -316,7 +316,7 @@ static __global__ __launch_bounds__(64) void k_spectra_512(const uint32_t *__res
 static __global__ __launch_bounds__(64) void k_to_fourier_512(const uint32_t *__restrict__ polys, double *__restrict__ spectra,
                                                               const cd *__restrict__ twt, int count)
 {
-    __shared__ cd sc[kScratchSlots];
+    __shared__ cd sc[kScratchSlots512];
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
     const int polyIdx = 2 * blockIdx.x + h;
     const bool live = polyIdx < count;
@@ -341,7 +341,7 @@ static __global__ __launch_bounds__(64) void k_to_fourier_512(const uint32_t *__
 static __global__ __launch_bounds__(64) void k_to_poly_512(const double *__restrict__ spectra, uint32_t *__restrict__ polys,
                                                            const cd *__restrict__ twt, int count)
 {
-    __shared__ cd sc[kScratchSlots];
+    __shared__ cd sc[kScratchSlots512];
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
     const int polyIdx = 2 * blockIdx.x + h;
     const bool live = polyIdx < count;

@@ -154,7 +154,7 @@ static __global__ __launch_bounds__(64) void k_keygen_bsk_512(cd *__restrict__ b
                                                                const cd *__restrict__ s1_spec /* [8][32] */,
                                                                const uint32_t *__restrict__ s0, double alpha, Seed128 seed)
 {
-    __shared__ cd sc[kScratchSlots];
+    __shared__ cd sc[kScratchSlots512];
     const int lane = threadIdx.x, h = lane >> 5, hl = lane & 31;
     const int i = blockIdx.x, row = 2 * i + h;
     cd *sch = sc + h * kHalfScratch;

@@ -102,7 +102,22 @@ __device__ __forceinline__ void wave_lds_order()
 // stride both exchange patterns are conflict-free for ds_write_b128 (8 contiguous lanes ->
 // 8 contiguous slots) and ds_read_b128 (the four 16-lane service groups each touch 16
 // distinct slot residues mod 16).
+#ifdef FFT_UNPADDED
+// Unpadded variant (512 slots = 8 KiB per wave, for the occupancy experiment -DOCC3): the same two exchanges with
+// swizzled slots instead of padded rows; every ds_write_b128 pass hits 8 slot residues mod 8 and every ds_read_b128
+// service group 16 residues mod 16, in both directions (brute-force checked).
+constexpr int kScratchSlots = 512;
+#define SL1W(r) (64 * (r) + 8 * ((hi + (((r) >> 1) & 1)) & 7) + lo)            /* (reg r; lane hi,lo) exchange-1 store side */
+#define SL1R(r) (64 * hi + 8 * (((r) + ((hi >> 1) & 1)) & 7) + lo)              /* exchange-1 load side */
+#define SL2W(r) (64 * hi + 8 * (((r) + (hi >> 1)) & 7) + ((lo + (r)) & 7))      /* exchange-2 store side */
+#define SL2R(r) (64 * hi + 8 * ((lo + (hi >> 1)) & 7) + (((r) + lo) & 7))       /* exchange-2 load side */
+#else
 constexpr int kScratchSlots = 8 * 72;
+#define SL1W(r) (72 * (r) + lane)
+#define SL1R(r) (72 * hi + 8 * (r) + lo)
+#define SL2W(r) (72 * hi + 9 * (r) + lo)
+#define SL2R(r) (72 * hi + 9 * lo + (r))
+#endif
 
 // Twiddle table layout (built on the host in long double, tfhe_hip.cpp):
 //   [0..7]                 level-1 pre-twists      c1[a]  = zeta^(64 a)          (wave-uniform)
@@ -205,19 +220,19 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     dft8<1>(x);
     // exchange 1: (reg m, lane 8b+c) -> (reg b, lane 8m+c)
 #pragma unroll
-    for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];
+    for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[m];
     wave_lds_order();
 #pragma unroll
-    for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
+    for (int b = 0; b < 8; b++) x[b] = sc[SL1R(b)];
     wave_lds_order();
     twist_pow<false>(x, tw.l2);
     dft8<1>(x);
     // exchange 2: (reg m', lane 8m+c) -> (reg c, lane 8m+m')
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];
+    for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[mp];
     wave_lds_order();
 #pragma unroll
-    for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
+    for (int c = 0; c < 8; c++) x[c] = sc[SL2R(c)];
     wave_lds_order();
     twist_pow<false>(x, tw.l3);
     dft8<1>(x);
@@ -255,19 +270,19 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
     dft8<1>(x);
 #pragma unroll
-    for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[m];
+    for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[m];
     wave_lds_order();
 #pragma unroll
-    for (int b = 0; b < 8; b++) x[b] = sc[72 * hi + 8 * b + lo];
+    for (int b = 0; b < 8; b++) x[b] = sc[SL1R(b)];
     wave_lds_order();
     FFT_MIX1(64);
     twist_all(x, tw.l2, ts.l2);
     dft8<1>(x);
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[mp];
+    for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[mp];
     wave_lds_order();
 #pragma unroll
-    for (int c = 0; c < 8; c++) x[c] = sc[72 * hi + 9 * lo + c];
+    for (int c = 0; c < 8; c++) x[c] = sc[SL2R(c)];
     wave_lds_order();
     FFT_MIX1(64);
     twist_all(x, tw.l3, ts.l3);
@@ -281,19 +296,19 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
     dft8<-1>(x);
     twist_all_conj(x, tw.l3, ts.l3);
 #pragma unroll
-    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    for (int c = 0; c < 8; c++) sc[SL2R(c)] = x[c];
     wave_lds_order();
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[SL2W(mp)];
     wave_lds_order();
     FFT_MIX1(64);
     dft8<-1>(x);
     twist_all_conj(x, tw.l2, ts.l2);
 #pragma unroll
-    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    for (int b = 0; b < 8; b++) sc[SL1R(b)] = x[b];
     wave_lds_order();
 #pragma unroll
-    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    for (int m = 0; m < 8; m++) x[m] = sc[SL1W(m)];
     wave_lds_order();
     FFT_MIX1(64);
     dft8<-1>(x);
@@ -318,10 +333,10 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
         dft8<1>(x[t]);
         TFHE_PRIO(3);
 #pragma unroll
-        for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];
+        for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[t][m];
         wave_lds_order();
 #pragma unroll
-        for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];
+        for (int b = 0; b < 8; b++) x[t][b] = sc[SL1R(b)];
         wave_lds_order();
         TFHE_PRIO(0);
     }
@@ -332,10 +347,10 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
         dft8<1>(x[t]);
         TFHE_PRIO(3);
 #pragma unroll
-        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];
+        for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[t][mp];
         wave_lds_order();
 #pragma unroll
-        for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];
+        for (int c = 0; c < 8; c++) x[t][c] = sc[SL2R(c)];
         wave_lds_order();
         TFHE_PRIO(0);
     }
@@ -359,18 +374,18 @@ __device__ __forceinline__ void fft512_forward_batch_pipe(cd (&x)[NB][8], cd *sc
     const int hi = lane >> 3, lo = lane & 7;
     auto xchg1 = [&](int t) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) sc[72 * m + lane] = x[t][m];
+        for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[t][m];
         wave_lds_order();
 #pragma unroll
-        for (int b = 0; b < 8; b++) x[t][b] = sc[72 * hi + 8 * b + lo];
+        for (int b = 0; b < 8; b++) x[t][b] = sc[SL1R(b)];
         wave_lds_order();
     };
     auto xchg2 = [&](int t) {
 #pragma unroll
-        for (int mp = 0; mp < 8; mp++) sc[72 * hi + 9 * mp + lo] = x[t][mp];
+        for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[t][mp];
         wave_lds_order();
 #pragma unroll
-        for (int c = 0; c < 8; c++) x[t][c] = sc[72 * hi + 9 * lo + c];
+        for (int c = 0; c < 8; c++) x[t][c] = sc[SL2R(c)];
         wave_lds_order();
     };
     auto mix = [&]() {          // the region just written: 1 DS op per FFT_PIPE_VALU VALU ops, stores first
@@ -425,19 +440,19 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
     twist_pow<true>(x, tw.l3);
     // (reg c, lane 8m+m') -> (reg m', lane 8m+c)
 #pragma unroll
-    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    for (int c = 0; c < 8; c++) sc[SL2R(c)] = x[c];
     wave_lds_order();
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[SL2W(mp)];
     wave_lds_order();
     dft8<-1>(x);
     twist_pow<true>(x, tw.l2);
     // (reg b, lane 8m+c) -> (reg m, lane 8b+c)
 #pragma unroll
-    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    for (int b = 0; b < 8; b++) sc[SL1R(b)] = x[b];
     wave_lds_order();
 #pragma unroll
-    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    for (int m = 0; m < 8; m++) x[m] = sc[SL1W(m)];
     wave_lds_order();
     dft8<-1>(x);
 #pragma unroll
@@ -464,19 +479,19 @@ __device__ __forceinline__ void fft512_inverse_pipe(cd (&x)[8], cd *sc, const cd
     dft8<-1>(x);
     twist_pow<true>(x, tw.l3);
 #pragma unroll
-    for (int c = 0; c < 8; c++) sc[72 * hi + 9 * lo + c] = x[c];
+    for (int c = 0; c < 8; c++) sc[SL2R(c)] = x[c];
     wave_lds_order();
 #pragma unroll
-    for (int mp = 0; mp < 8; mp++) x[mp] = sc[72 * hi + 9 * mp + lo];
+    for (int mp = 0; mp < 8; mp++) x[mp] = sc[SL2W(mp)];
     wave_lds_order();
     mix();
     dft8<-1>(x);
     twist_pow<true>(x, tw.l2);
 #pragma unroll
-    for (int b = 0; b < 8; b++) sc[72 * hi + 8 * b + lo] = x[b];
+    for (int b = 0; b < 8; b++) sc[SL1R(b)] = x[b];
     wave_lds_order();
 #pragma unroll
-    for (int m = 0; m < 8; m++) x[m] = sc[72 * m + lane];
+    for (int m = 0; m < 8; m++) x[m] = sc[SL1W(m)];
     wave_lds_order();
     mix();
     dft8<-1>(x);
