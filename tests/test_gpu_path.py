@@ -367,6 +367,33 @@ def test_committed_golden_vectors_on_gpu(pkg, oracle):
         ck.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_random_batches_every_entry_point_agrees(oracle, keys_small, ck_small, pkg, seed):
+    # Randomised cross-check of the dispatch machinery: a random batch size (any launcher range), random per-item
+    # gates incl. MUX.  The host-pointer call, the device-pointer call and the same items issued in random pieces give
+    # the same words; a sample is compared with the oracle.
+    import torch
+    k = keys_small
+    rs = np.random.RandomState(7000 + seed)
+    B = int(rs.choice([rs.randint(1, 40), rs.randint(200, 300), rs.randint(500, 800), rs.randint(1000, 1100), rs.randint(1500, 2600)]))
+    a, b, c = (rand_u32(rs, (B, k.p.n + 1)) for _ in range(3))
+    pool = [x for x in pkg.OPS if x != "MUX"] + ["MUX"] * 3
+    ops = np.array([pkg.OPS[pool[i]] for i in rs.randint(0, len(pool), B)], np.uint8)
+    host = ck_small.ctx.gate_batch(ops, a, b, c)
+    ad, bd, cdv = (torch.from_numpy(v.view(np.int32)).cuda() for v in (a, b, c))
+    od = torch.empty_like(ad)
+    ck_small.ctx.gate_batch_dev(torch.from_numpy(ops).cuda(), ad, bd, cdv, od)
+    torch.cuda.synchronize()
+    assert np.array_equal(od.cpu().numpy().view(np.uint32), host), (seed, B)
+    cuts = sorted(set([0, B] + list(rs.randint(0, B + 1, 3))))
+    pieces = np.concatenate([ck_small.ctx.gate_batch(ops[i:j], a[i:j], b[i:j], c[i:j]) for i, j in zip(cuts[:-1], cuts[1:]) if j > i])
+    assert np.array_equal(pieces, host), (seed, B, cuts)
+    sample = sorted(set(rs.randint(0, B, 6)))
+    ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops[sample], np.ascontiguousarray(a[sample]), np.ascontiguousarray(b[sample]),
+                               np.ascontiguousarray(c[sample]))
+    assert np.array_equal(host[sample], ref), (seed, B)
+
+
 def test_host_pointer_batches_longer_than_a_slab(oracle, keys_small, ck_small, pkg):
     # tfhe_gate_batch on more than one slab (16,384 bootstraps) moves slab s+1's operands up and slab s-1's results down
     # while slab s computes (double-buffered staging, three streams).  Same words as the same items issued in pieces that
