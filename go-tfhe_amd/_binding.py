@@ -69,6 +69,8 @@ def load_library():
         "tfhe_key_size": [vp, C.c_int, C.POINTER(C.c_size_t)],
         "tfhe_key_export_dev": [vp, C.c_int, vp, vp],
         "tfhe_key_import_dev": [vp, C.c_int, vp, vp],
+        "tfhe_key_export": [vp, C.c_int, vp],
+        "tfhe_key_import": [vp, C.c_int, vp],
         "tfhe_keygen_cloud_seeded": [vp, u32p, u32p, C.c_double, C.c_double, C.POINTER(C.c_uint64)],
         "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
         "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
@@ -372,6 +374,18 @@ class Context:
         n = C.c_size_t()
         self._check(self._lib.tfhe_key_size(self._h, int(which), C.byref(n)))
         return n.value
+
+    def key_export(self, which):
+        """The loaded key `which` as an opaque numpy uint8 array (host memory; save it, ship it, key_import it)."""
+        blob = np.empty(self.key_size(which), np.uint8)
+        self._check(self._lib.tfhe_key_export(self._h, int(which), blob.ctypes.data_as(C.c_void_p)))
+        return blob
+
+    def key_import(self, which, blob):
+        blob = np.ascontiguousarray(blob, np.uint8)
+        if blob.size != self.key_size(which):
+            raise ValueError(f"key blob: expected {self.key_size(which)} bytes, got {blob.size}")
+        self._check(self._lib.tfhe_key_import(self._h, int(which), blob.ctypes.data_as(C.c_void_p)))
 
     def key_export_dev(self, which, stream=None):
         """The loaded key `which` (0 = bootstrapping, 1 = key-switching) as an opaque uint8 GPU tensor."""

@@ -853,6 +853,38 @@ int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, void *stream)
     return TFHE_OK;
 }
 
+// Host-memory forms of the blobs (persist a GPU-generated cloud key, hand it to another process / machine).
+int tfhe_key_export(tfhe_ctx *c, int which, void *dst)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!dst || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (which == 0 ? !c->have_bsk : !c->have_ksk) return fail(TFHE_E_NOKEY, "key not loaded");
+    size_t bytes;
+    tfhe_key_size(c, which, &bytes);
+    HIP_TRY(hipMemcpyAsync(dst, which == 0 ? c->bsk.p : c->ksk.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_key_import(tfhe_ctx *c, int which, const void *src)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!src || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    size_t bytes;
+    tfhe_key_size(c, which, &bytes);
+    DevBuf &dstbuf = which == 0 ? c->bsk : c->ksk;
+    if ((rc = dstbuf.reserve(bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(dstbuf.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (which == 0 && (rc = make_quad_key(c, c->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (which == 0 ? c->have_bsk : c->have_ksk) = true;
+    return TFHE_OK;
+}
+
 int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
                       uint64_t seed)
 {

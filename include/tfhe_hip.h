@@ -132,6 +132,10 @@ int tfhe_keygen_cloud(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *s1, dou
 int tfhe_key_size(tfhe_ctx *ctx, int which, size_t *bytes);
 int tfhe_key_export_dev(tfhe_ctx *ctx, int which, void *d_dst, void *stream);
 int tfhe_key_import_dev(tfhe_ctx *ctx, int which, const void *d_src, void *stream);
+/* The same blobs through HOST memory (tfhe_key_size bytes): persist a GPU-generated cloud key, or hand it to another
+ * process; synchronous. */
+int tfhe_key_export(tfhe_ctx *ctx, int which, void *dst);
+int tfhe_key_import(tfhe_ctx *ctx, int which, const void *src);
 
 /* Evaluator.BootstrapAssign / BootstrapLUTAssign over a batch (evaluator.go:139-148,
  * programmable_bootstrap.go:93-115; batch fan-out trgsw.go:234-252).

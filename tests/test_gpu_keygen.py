@@ -116,6 +116,29 @@ def test_default_seed_is_os_entropy(oracle, pkg):
         pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=1 << 128)
 
 
+def test_key_blobs_through_host_memory(oracle, pkg, tmp_path):
+    # tfhe_key_export / tfhe_key_import: a GPU-generated cloud key saved to disk and loaded into a fresh context (any
+    # N: here the N = 512 ring of Uint2 and the 128-bit gate set) evaluates identically, word for word.
+    for name in ("128", "uint2"):
+        p = oracle.params(name).small(10)
+        rng = oracle.rng(0x7F4E0046)
+        s0, s1 = oracle.keygen_secret(p, rng)
+        ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=77)
+        cts = np.stack([oracle.encrypt_message(p, rng, m % 2, 2, s0) for m in range(6)])
+        lut = oracle.lut_generate(p, [1, 0])
+        want = ck.ctx.bootstrap_batch(cts, lut)
+        for which in (0, 1):
+            np.save(tmp_path / f"{name}_{which}.npy", ck.ctx.key_export(which))
+        ck.close()
+        ck2 = pkg.CloudKey(gpu_params(pkg, p))
+        for which in (0, 1):
+            ck2.ctx.key_import(which, np.load(tmp_path / f"{name}_{which}.npy"))
+        assert np.array_equal(ck2.ctx.bootstrap_batch(cts, lut), want), name
+        with pytest.raises(ValueError):
+            ck2.ctx.key_import(0, np.zeros(16, np.uint8))
+        ck2.close()
+
+
 def _wave_blob_to_reference_spectra(blob, n, L):
     """Device layout cd bsk[n][2][L][2][8][64] (csrc/kernels.hpp) -> reference FourierPoly layout [n][2L][2][1024]:
     (reg, lane) holds root u = (lane>>3) + 8*(lane&7) + 64*reg, the reference keeps it in slot bitrev9(-u mod 512),
