@@ -282,8 +282,9 @@ def main():
                                            "reuse_factor": (alg / traffic) if traffic else None},
                          "note": "SURVEY 8d's streaming model (every bootstrap reads the whole 68.8 MB key) does not bound this "
                                  "kernel: the 1024 bootstraps of a launch walk the key in step and each XCD's L2 fetches it once "
-                                 "(measured traffic = 8 x 68.8 MB), so the algorithmic rate exceeds the HBM peak; the binding "
-                                 "resource is fp64 vector issue (163.4 Mflop per bootstrap)"},
+                                 "(measured traffic = 8 x 68.8 MB), so the algorithmic rate exceeds the HBM peak; what binds is "
+                                 "vector-instruction issue (163.4 Mflop of fp64 per bootstrap) together with the LDS store path of "
+                                 "the FFT exchanges (DESIGN.md section 3, PMC analysis)"},
             "verification": {"all_1024_decrypt_to_NAND": dec_ok, "sampled_outputs_bit_identical_to_oracle": bit_ok,
                              "sample": sample, "of": "the output buffer the last timed step wrote (zeroed before the timed region)"},
             "kernels": {"k_blind_rotate_ms": br_avg_ms, "k_extract_keyswitch_ms": ks_avg_ms,
