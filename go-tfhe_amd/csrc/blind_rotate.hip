@@ -2,13 +2,14 @@
 // Separate translation unit: built with -mllvm -amdgpu-sched-strategy=max-ilp (see build.py).
 #include "launch_blind_rotate.hpp"
 
+
 #include "kernels_n2048.hpp"
 #include "kernels_n512.hpp"
 #include "kernels_quad.hpp"
 
 namespace tfhe {
 
-void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cus, int quad_limit, hipStream_t st)
+void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cus, int quad_limit, int oct_limit, hipStream_t st)
 {
     // One launch covers at most the number of co-resident workgroups (28.8 KB LDS / 256 VGPRs -> 4 per CU
     // for N=1024; 55 KB LDS -> 2 per CU for N=2048).  All workgroups of such a launch walk the CMUX index in
@@ -31,7 +32,10 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         const dim3 g(cnt);
         if (shape_is_1024(shape) && cnt <= quad_max) {
             // one workgroup per CU: one wave per SIMD, all key levels prefetched; two per CU: two waves per SIMD
-            if (cnt <= num_cus) {
+            if (cnt <= num_cus && cnt <= oct_limit && shape == kShapeN1024_L3_B6) {
+                // one bootstrap per CU on eight waves
+                hipLaunchKernelGGL((k_blind_rotate_oct<3, 6>), g, dim3(512), 0, st, a);
+            } else if (cnt <= num_cus) {
                 switch (shape) {
                 case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 1>), g, dim3(256), 0, st, a); break;
                 case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate_quad<2, 10, 1, 1>), g, dim3(256), 0, st, a); break;

@@ -462,4 +462,219 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
     report_bad_op(A, bad_op, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Eight waves per bootstrap (launches of at most one bootstrap per CU): the four (p, h) waves above, twice.
+// Group 0 transforms gadget levels [0, L0) and group 1 levels [L0, L) of the same (p, h) half-polynomial, so the
+// forward phase of a CMUX step is ceil(L/2) transforms deep instead of L and both waves of a SIMD issue side by
+// side.  Group 1 then gathers the four partial products of its output half (its own, group 0's, and the partner
+// polynomial's two), runs the one inverse transform and publishes the result; all eight waves apply the update to
+// their private copy of the accumulator.  Two barriers per step, as in the four-wave kernel.
+// Phase clock of the eight-wave kernel (tools/oct_trace.py; -DOCT_TRACE builds only): per-wave sums of the shader
+// clock between marks, stored over the output at the end.  Each mark drains the wave's outstanding memory operations.
+#ifndef OCT_KEY_GAP
+#define OCT_KEY_GAP 8
+#endif
+struct OctTrace {
+#ifdef OCT_TRACE
+    long long sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prev = 0;
+    __device__ __forceinline__ void start() { __builtin_amdgcn_sched_barrier(0); prev = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    __device__ __forceinline__ void mark(int k)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long now = clock64();
+        sum[k] += now - prev;
+        prev = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+
+template <int L, int BGBIT, int LB, int NL>
+__device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint32_t *acc /* signed table */,
+                                            const uint32_t (&areg)[4][4], int at, double sr, int lane, int p,
+                                            const cd *__restrict__ key_iph /* &bskq[i][p][h][0] */, cd *sc,
+                                            const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q, cd (&keep)[4],
+                                            cd (&send)[4], OctTrace &tr)
+{
+    constexpr int N = 1024;
+    constexpr uint32_t mask = (1u << BGBIT) - 1u;
+    constexpr int half = 1 << (BGBIT - 1);
+    QuadKeys K[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) load_quad_keys(K[l], key_iph + (size_t)(LB + l) * 512, p, lane);
+#ifdef OCT_KEYS_FIRST
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    cd x[NL][4];
+    const int base = lane - at;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        uint32_t dd[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)         // X^at * acc straight from the signed table: entry s >= N is ~acc[s - N]
+            dd[k] = acc[(base + 64 * a + 256 * k) & (2 * N - 1)] - areg[a][k] + A.offset;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            const int shift = 32 - (LB + l + 1) * BGBIT;
+            const int lo_re = (int)((dd[0] >> shift) & mask) - half, hi_re = (int)((dd[1] >> shift) & mask) - half;
+            const int lo_im = (int)((dd[2] >> shift) & mask) - half, hi_im = (int)((dd[3] >> shift) & mask) - half;
+            x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
+        }
+    }
+#ifndef OCT_KEYS_FIRST
+    // the gather first, then the key loads trickle out between the digit arithmetic: eight waves issuing 8 NL loads
+    // back to back queue behind each other at the CU's one address path and start the decomposition late
+    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+    for (int t = 0; t < 8 * NL; t++) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, OCT_KEY_GAP, 0);
+    }
+#endif
+    tr.mark(0);
+    if constexpr (NL > 1) fft256_forward_batch_pipe<NL>(x, sc, T, tw, q);
+    else fft256_forward_batch<NL>(x, sc, T, tw, q);
+    tr.mark(1);
+#pragma unroll
+    for (int l = 0; l < NL; l++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (l == 0) {
+                keep[k] = cmul(x[0][k], K[0].keep[k]);
+                send[k] = cmul(x[0][k], K[0].send[k]);
+            } else {
+                cfma(keep[k], x[l][k], K[l].keep[k]);
+                cfma(send[k], x[l][k], K[l].send[k]);
+            }
+        }
+}
+
+template <int L, int BGBIT>
+__global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
+{
+    static_assert(L >= 2, "one gadget level has nothing to split");
+    constexpr int N = 1024, L0 = (L + 1) / 2, L1 = L - L0;
+    constexpr double r = 0.70710678118654752440;
+    __shared__ cd scAll[8][256];            // FFT exchanges; a group-0 wave also leaves its products for its own half here
+    __shared__ cd sendG[2][4][256];         // products for the partner polynomial, by group
+    __shared__ cd swapAll[4][256];          // inverse transform results, for the half swap
+    __shared__ uint32_t accAll[8][2 * N];   // per wave: the accumulator polynomial and its complement = the 2N-periodic
+                                            // signed table T[s] = (X^s-coefficient sign) so X^a*acc is a plain gather
+    __shared__ uint16_t abarL[kMaxLweDim];
+    __shared__ int btL;
+
+    const int lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int g = w >> 2, ph = w & 3, p = ph >> 1, h = ph & 1;
+    uint32_t *acc = accAll[w];
+    cd *sc = scAll[w];
+    const int item = A.first + blockIdx.x;
+    if (!gate_item_live(A, item)) return;
+    const bool bad_op = gate_prep_modswitch(A, item, tid, 512, N, abarL, &btL);
+    const cd *T = A.twq + (size_t)h * kTwQuadHalf;
+    QuadTwiddles tw;
+    load_quad_twiddles(tw, T, lane);
+    const QuadLane q = quad_lane(lane);
+    __syncthreads();
+    // the wave's copy of polynomial p: coefficient 64a + lane + 256k in areg[a][k], mirrored into the signed table
+    uint32_t areg[4][4];
+    {
+        const int bt = btL & (2 * N - 1);
+        const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 64 * a + lane + 256 * k;
+                const int s = (j - bt) & (2 * N - 1);
+                uint32_t v = tv[s & (N - 1)];
+                v ^= 0u - (uint32_t)((s >> 10) & 1);
+                areg[a][k] = v;
+                acc[j] = v;
+                acc[j + N] = ~v;
+            }
+    }
+    wave_lds_order();
+
+    constexpr size_t kStep = (size_t)2 * L * 2 * 512;
+    const cd *key = A.bskq + ((size_t)p * 2 + h) * (L * 2 * 256);
+    const int partner = ph ^ 2, sibling = ph ^ 1;
+    const double sr = h ? -r : r;
+    constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;
+    const int nsteps = A.nsteps;
+    OctTrace tr;
+    tr.start();
+    for (int i = 0; i < nsteps; i++) {
+        const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        cd keep[4], send[4];
+        if (g == 0) {
+            oct_forward<L, BGBIT, 0, L0>(A, acc, areg, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sc[k * 64 + lane] = keep[k];
+                sendG[0][ph][k * 64 + lane] = send[k];
+            }
+        } else {
+            oct_forward<L, BGBIT, L0, L1>(A, acc, areg, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
+#pragma unroll
+            for (int k = 0; k < 4; k++) sendG[1][ph][k * 64 + lane] = send[k];
+        }
+        tr.mark(2);
+        __syncthreads();
+        tr.mark(3);
+        if (g == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                keep[k] = (keep[k] + scAll[ph][k * 64 + lane]) + (sendG[0][partner][k * 64 + lane] + sendG[1][partner][k * 64 + lane]);
+            tr.mark(4);
+            fft256_inverse(keep, sc, T, tw, q);
+#pragma unroll
+            for (int k = 0; k < 4; k++) swapAll[ph][k * 64 + lane] = keep[k];
+            tr.mark(5);
+        }
+        __syncthreads();
+        tr.mark(6);
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const cd own = swapAll[ph][a * 64 + lane], o = swapAll[sibling][a * 64 + lane];
+            const cd s = own + o, dl = own - o;
+            const double e1r = (dl.re + dl.im) * sr, e1i = (dl.im - dl.re) * sr;
+            areg[a][0] += kSmall ? round_to_torus_small(s.re) : round_to_torus_wide(s.re);
+            areg[a][2] += kSmall ? round_to_torus_small(s.im) : round_to_torus_wide(s.im);
+            areg[a][1] += kSmall ? round_to_torus_small(e1r) : round_to_torus_wide(e1r);
+            areg[a][3] += kSmall ? round_to_torus_small(e1i) : round_to_torus_wide(e1i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = 64 * a + lane + 256 * k;
+                acc[j] = areg[a][k];
+                acc[j + N] = ~areg[a][k];
+            }
+        }
+        wave_lds_order();
+        tr.mark(7);
+    }
+#ifdef OCT_TRACE
+    if (lane < 10) {
+        long long v = 0;
+#pragma unroll
+        for (int k = 0; k < 10; k++) v = lane == k ? tr.sum[k] : v;
+        reinterpret_cast<long long *>(A.out + (size_t)item * 2 * N)[w * 16 + lane] = v;
+    }
+    return;
+#endif
+
+    if (g == 0) {
+        uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            out[64 * a + lane + 256 * h] = areg[a][h];
+            out[64 * a + lane + 256 * h + 512] = areg[a][2 + h];
+        }
+    }
+    report_bad_op(A, bad_op, tid);
+}
+
 } // namespace tfhe

@@ -18,8 +18,9 @@ enum Shape { kShapeN1024_L3_B6 = 1,   // 80/110/128-bit sets
 inline bool shape_is_1024(int shape) { return shape != kShapeN2048_L1_B22 && shape != kShapeN512_L1_B18; }
 inline bool shape_is_512(int shape) { return shape == kShapeN512_L1_B18; }
 // B items in launches of at most the co-resident workgroup count (4 per CU for N=1024, 2 per CU for N=2048).
-// quad_limit: N = 1024 launches of up to this many items use the four-wave kernel (kernels_quad.hpp).
-void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, int num_cus, int quad_limit, hipStream_t st);
+// quad_limit: N = 1024 launches of up to this many items use the four-wave kernel (kernels_quad.hpp);
+// oct_limit: of those, launches of up to this many (and at most one per CU) use the eight-wave kernel.
+void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, int num_cus, int quad_limit, int oct_limit, hipStream_t st);
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
                              uint32_t offset, int B, hipStream_t st);
 } // namespace tfhe

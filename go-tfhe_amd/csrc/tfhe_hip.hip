@@ -87,6 +87,7 @@ struct tfhe_ctx {
     hipEvent_t pipe_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};      // [in, done, out][buffer]
     hipStream_t last_dev_stream = nullptr;      // stream of the most recent _dev call (tfhe_ctx_sync waits for it too)
     bool last_dev_stream_set = false;
+    int oct_limit = 0;          // ... and of up to this many the eight-wave kernel (one bootstrap per CU)
     int quad_limit = 0;         // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
     hipStream_t stream = nullptr;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -283,7 +284,7 @@ int launch_blind_rotate(tfhe_ctx *c, const RotateJob &j, hipStream_t st)
     hipEvent_t stop;
     int trc = timing_begin(c, 0, st, &stop);
     if (trc) return trc;
-    launch_blind_rotate(c->shape, a, j.B, c->num_cus, c->quad_limit, st);
+    launch_blind_rotate(c->shape, a, j.B, c->num_cus, c->quad_limit, c->oct_limit, st);
     HIP_TRY(hipGetLastError());
     return timing_end(c, 0, st, stop);
 }
@@ -600,6 +601,8 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
         // tuning override for A/B measurements (tools/): TFHE_QUAD_MAX=0 keeps every launch on the two-wave kernel
         const char *e = getenv("TFHE_QUAD_MAX");
         c->quad_limit = e ? atoi(e) : c->num_cus;
+        e = getenv("TFHE_OCT_MAX");
+        c->oct_limit = e ? atoi(e) : c->num_cus;
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)

@@ -310,7 +310,7 @@ def test_dispatch_boundaries_gate_shape(oracle, keys_small, ck_small, pkg, B):
 
 @pytest.mark.parametrize("which", ["small", "uint1", "uint3"])
 def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which, monkeypatch):
-    # kernels_quad.hpp (launches of <= one workgroup per CU) against kernels.hpp on the same key and inputs: the
+    # kernels_quad.hpp (four waves per bootstrap; eight for L = 3 at <= one bootstrap per CU) against kernels.hpp on the same key and inputs: the
     # accumulators are bit-identical word for word at every prefix of the CMUX chain, for all three N = 1024
     # gadget shapes (L=3/Bg=2^6: exact regime, whole chains; Uint1 L=2/Bg=2^10 and Uint3 L=1/Bg=2^23: tolerance
     # regime, one product).
@@ -324,7 +324,11 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
     ck2 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
     monkeypatch.setenv("TFHE_QUAD_MAX", "1000000")
     ck4 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
+    # ... and with the eight-wave kernel switched off (it serves L = 3 launches of at most one bootstrap per CU)
+    monkeypatch.setenv("TFHE_OCT_MAX", "0")
+    ck4only = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk) if which == "small" else None
     monkeypatch.delenv("TFHE_QUAD_MAX")
+    monkeypatch.delenv("TFHE_OCT_MAX")
     rs = np.random.RandomState(21)
     for B in (1, 5, 300):            # 300 > one workgroup per CU: the two-per-CU instance of the four-wave kernel
         cts = rand_u32(rs, (B, p.n + 1))
@@ -334,6 +338,7 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
             a, b = ck2.ctx.blind_rotate_batch(cts, tvs, nsteps), ck4.ctx.blind_rotate_batch(cts, tvs, nsteps)
             if which == "small":
                 assert np.array_equal(a, b), (B, nsteps)
+                assert np.array_equal(a, ck4only.ctx.blind_rotate_batch(cts, tvs, nsteps)), (B, nsteps)
             else:
                 # values reach 2^52 / 2^64 here: not exact integers for any fp64 pipeline, and one
                 # differing low bit flips a digit of the next step, so only ONE product is comparable: the two
@@ -342,6 +347,8 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
                 diff = (a.astype(np.int64) - b.astype(np.int64) + 2**31) % 2**32 - 2**31
                 assert np.abs(diff).max() <= tol, (which, B, nsteps, np.abs(diff).max())
     ck2.close(); ck4.close()
+    if ck4only is not None:
+        ck4only.close()
 
 
 def test_committed_golden_vectors_on_gpu(pkg, oracle):
