@@ -157,6 +157,39 @@ constexpr int kMaxLweDim = 1280;      // Uint7/8 use n = 1160 (params.go:444-510
 // Key slices of one gadget level for one wave: 8 register-slices of the spectrum it keeps and
 // 8 of the spectrum it hands to its partner (64 VGPRs), fetched one level ahead of use so the
 // L2/MALL latency hides under the forward FFT in between.
+// Phase clock of the blind-rotate kernels (tools/phase_trace.py; -DPHASE_TRACE builds only): per-wave sums of the
+// shader clock between marks, stored over the kernel's output at the end.  A mark drains the wave's LDS operations.
+struct PhaseClock {
+#ifdef PHASE_TRACE
+    long long sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prev = 0;
+    __device__ __forceinline__ void start() { __builtin_amdgcn_sched_barrier(0); prev = clock64(); __builtin_amdgcn_sched_barrier(0); }
+    // PHASE_TRACE = 1 keeps only the marks around the first barrier of a step (2, 3: the wave has drained its LDS
+    // operations there anyway) and lumps everything else into mark 7: the timeline of an almost undisturbed kernel
+    __device__ __forceinline__ void mark(int k)
+    {
+        if (PHASE_TRACE == 1 && k != 2 && k != 3 && k != 7) return;
+        __builtin_amdgcn_sched_barrier(0);
+        const long long now = clock64();
+        sum[k] += now - prev;
+        prev = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // wave `slot` of the item stores its sums into the item's output row (the result is lost: trace builds only)
+    __device__ __forceinline__ void store(uint32_t *out_item, int slot, int lane) const
+    {
+        if (lane < 10) {
+            long long v = 0;
+#pragma unroll
+            for (int k = 0; k < 10; k++) v = lane == k ? sum[k] : v;
+            reinterpret_cast<long long *>(out_item)[slot * 16 + lane] = v;
+        }
+    }
+#else
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+
 struct KeyRegs {
     cd keep[8], send[8];
 };
@@ -207,7 +240,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
                                                       KeyRegs &K, /* in: level 0 of this step; out: key_next */
                                                       cd *sc_mine, const cd *sc_other,
                                                       const cd *__restrict__ table, const LaneTwiddles &tw,
-                                                      uint32_t offset, int p, int lane)
+                                                      uint32_t offset, int p, int lane, PhaseClock &clk)
 {
     cd keep[8], send[8];
     // All L digit polynomials are transformed as one batch (fft512_forward_batch), then
@@ -226,6 +259,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
             }
         }
     }
+    clk.mark(0);
 #ifdef FFT_PIPE
 #ifdef LATE_KEYS
     // level-0 key slices are requested here, under the last level of the forward transforms (~260 fp64
@@ -243,6 +277,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 #else
     fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
 #endif
+    clk.mark(1);
 #pragma unroll
     for (int l = 0; l < L; l++) {
 #pragma unroll
@@ -280,10 +315,14 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
     }
 #endif
+    clk.mark(2);
     __syncthreads();
+    clk.mark(3);
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
+    clk.mark(4);
     __syncthreads();
+    clk.mark(5);
 #ifdef FFT_PIPE_INV
     fft512_inverse_pipe(keep, sc_mine, table, tw, lane);
 #else
@@ -298,6 +337,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         e[a] = kSmall ? round_to_torus_small(keep[a].re) : round_to_torus_wide(keep[a].re);
         e[a + 8] = kSmall ? round_to_torus_small(keep[a].im) : round_to_torus_wide(keep[a].im);
     }
+    clk.mark(6);
 }
 
 // ITEMS = 2 puts two bootstraps (four waves) in one workgroup.  The hardware places the waves of ONE
@@ -365,19 +405,26 @@ __global__ __launch_bounds__(128 * ITEMS, BR_MIN_WAVES(ITEMS)) void k_blind_rota
 #ifndef LATE_KEYS
     if (nsteps > 0) load_keys(K, key, p, lane);
 #endif
+    PhaseClock clk;
+    clk.start();
     for (int i = 0; i < nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
         const DiffSource S{accL[p], at, nullptr};
         external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, i + 1 < nsteps ? key + (size_t)(i + 1) * kStep : nullptr,
-                                        K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane);
+                                        K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane, clk);
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
         for (int q = 0; q < 16; q++) accL[p][64 * q + lane] += e[q];
         wave_lds_order();
+        clk.mark(7);
     }
 
     if (!live) return;
+#ifdef PHASE_TRACE
+    clk.store(A.out + (size_t)item * 2 * N, p, lane);
+    return;
+#endif
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) out[64 * q + lane] = accL[p][64 * q + lane];
@@ -403,7 +450,8 @@ __global__ __launch_bounds__(128, 2) void k_external_product(const cd *bsk, cons
 #ifndef LATE_KEYS
     load_keys(K, key, p, lane);
 #endif
-    external_product_core<L, BGBIT>(S, e, key, nullptr, K, sc[p], sc[p ^ 1], twt, tw, offset, p, lane);
+    PhaseClock clk;
+    external_product_core<L, BGBIT>(S, e, key, nullptr, K, sc[p], sc[p ^ 1], twt, tw, offset, p, lane, clk);
     uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) dst[64 * q + lane] = e[q];

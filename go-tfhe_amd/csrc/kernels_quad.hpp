@@ -469,35 +469,15 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
 // side.  Group 1 then gathers the four partial products of its output half (its own, group 0's, and the partner
 // polynomial's two), runs the one inverse transform and publishes the result; all eight waves apply the update to
 // their private copy of the accumulator.  Two barriers per step, as in the four-wave kernel.
-// Phase clock of the eight-wave kernel (tools/oct_trace.py; -DOCT_TRACE builds only): per-wave sums of the shader
-// clock between marks, stored over the output at the end.  Each mark drains the wave's outstanding memory operations.
 #ifndef OCT_KEY_GAP
 #define OCT_KEY_GAP 8
 #endif
-struct OctTrace {
-#ifdef OCT_TRACE
-    long long sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prev = 0;
-    __device__ __forceinline__ void start() { __builtin_amdgcn_sched_barrier(0); prev = clock64(); __builtin_amdgcn_sched_barrier(0); }
-    __device__ __forceinline__ void mark(int k)
-    {
-        __builtin_amdgcn_sched_barrier(0);
-        const long long now = clock64();
-        sum[k] += now - prev;
-        prev = now;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#else
-    __device__ __forceinline__ void start() {}
-    __device__ __forceinline__ void mark(int) {}
-#endif
-};
-
 template <int L, int BGBIT, int LB, int NL>
 __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint32_t *acc /* signed table */,
                                             const uint32_t (&areg)[4][4], int at, double sr, int lane, int p,
                                             const cd *__restrict__ key_iph /* &bskq[i][p][h][0] */, cd *sc,
                                             const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q, cd (&keep)[4],
-                                            cd (&send)[4], OctTrace &tr)
+                                            cd (&send)[4], PhaseClock &tr)
 {
     constexpr int N = 1024;
     constexpr uint32_t mask = (1u << BGBIT) - 1u;
@@ -605,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
     const double sr = h ? -r : r;
     constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;
     const int nsteps = A.nsteps;
-    OctTrace tr;
+    PhaseClock tr;
     tr.start();
     for (int i = 0; i < nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
@@ -656,13 +636,8 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
         wave_lds_order();
         tr.mark(7);
     }
-#ifdef OCT_TRACE
-    if (lane < 10) {
-        long long v = 0;
-#pragma unroll
-        for (int k = 0; k < 10; k++) v = lane == k ? tr.sum[k] : v;
-        reinterpret_cast<long long *>(A.out + (size_t)item * 2 * N)[w * 16 + lane] = v;
-    }
+#ifdef PHASE_TRACE
+    tr.store(A.out + (size_t)item * 2 * N, w, lane);
     return;
 #endif
 
