@@ -167,7 +167,7 @@ struct PhaseClock {
     // operations there anyway) and lumps everything else into mark 7: the timeline of an almost undisturbed kernel
     __device__ __forceinline__ void mark(int k)
     {
-        if (PHASE_TRACE == 1 && k != 2 && k != 3 && k != 7) return;
+        if (PHASE_TRACE == 1 && k != 2 && k != 3 && k != 7) return;      // (two-wave N = 1024 kernel's numbering)
         __builtin_amdgcn_sched_barrier(0);
         const long long now = clock64();
         sum[k] += now - prev;

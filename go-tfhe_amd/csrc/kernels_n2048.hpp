@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
     constexpr size_t kStep = (size_t)2 * 2 * 1024;
     const int wpart = ((1 - p) << 1) | h;               // same half of the other polynomial
     const double sr = h ? -r : r;
+    PhaseClock clk;
+    clk.start();
     for (int i = 0; i < A.nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         const cd *kp = key + (size_t)i * kStep;
@@ -266,7 +268,9 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
             keep[q] = cd{fma(sr, t.re, lo.re), fma(sr, t.im, lo.im)};
             dx[w][q * 64 + lane] = cd{fma(-sr, t.re, lo.re), fma(-sr, t.im, lo.im)};
         }
+        clk.mark(0);
         __syncthreads();
+        clk.mark(1);
         cd y[8];
         if (h == 0) {
 #pragma unroll
@@ -284,14 +288,20 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
             sc[w][k * 64 + lane] = cmul(y[k], kSend[k * 64]);
             y[k] = cmul(y[k], kKeep[k * 64]);
         }
+        clk.mark(2);
         __syncthreads();
+        clk.mark(3);
 #pragma unroll
         for (int k = 0; k < 8; k++) y[k] = y[k] + sc[wpart][k * 64 + lane];
+        clk.mark(4);
         __syncthreads();
+        clk.mark(5);
         fft512_inverse(y, sc[w], table, tw, ts, lane);  // table carries conj(c1)/1024
 #pragma unroll
         for (int k = 0; k < 8; k++) sc[w][k * 64 + lane] = y[k];
+        clk.mark(6);
         __syncthreads();
+        clk.mark(7);
         uint32_t e[16];
 #pragma unroll
         for (int a = 0; a < 8; a++) {
@@ -307,9 +317,15 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
             accL[p][64 * a + lane + 512 * h] += e[a];
             accL[p][64 * a + lane + 512 * h + 1024] += e[a + 8];
         }
+        clk.mark(8);
         __syncthreads();
+        clk.mark(9);
     }
     if (!live) return;
+#ifdef PHASE_TRACE
+    clk.store(A.out + (size_t)item * 2 * N, w, lane);
+    return;
+#endif
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) {

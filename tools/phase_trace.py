@@ -15,9 +15,10 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--params", default="128", help="128 (N = 1024 kernels) or uint5 (the four-wave N = 2048 kernel)")
 args = ap.parse_args()
 pkg = g.load_package()
-p = pkg.params.BY_NAME["128"]
+p = pkg.params.BY_NAME[args.params]
 rs = np.random.RandomState(3)
 rnd = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
 ck = pkg.CloudKey(p, bsk_torus=rnd((p.n, 2 * p.L, 2, p.N)), ksk=rnd((p.ksk_rows, p.n + 1)))
@@ -26,12 +27,15 @@ c = torch.from_numpy(rnd((B, p.n + 1)).view(np.int32)).cuda()
 o = torch.zeros((B, 2, p.N), dtype=torch.int32, device="cuda")
 for _ in range(3): ck.ctx.blind_rotate_batch_dev(c, None, o)
 torch.cuda.synchronize()
-oct_kernel = B <= torch.cuda.get_device_properties(0).multi_processor_count
-W = 8 if oct_kernel else 2
-t = o.cpu().numpy().view(np.int64).reshape(B, -1)[:, :16 * W].reshape(B, W, 16)[:, :, :8] / p.n
-names = (["keys+dec", "forward", "mac+store", "barrier1", "gather", "inv+store", "barrier2", "update"] if oct_kernel else
+n2048 = p.N == 2048
+oct_kernel = not n2048 and B <= torch.cuda.get_device_properties(0).multi_processor_count
+W = 4 if n2048 else 8 if oct_kernel else 2
+NM = 10 if n2048 else 8
+t = o.cpu().numpy().view(np.int64).reshape(B, -1)[:, :16 * W].reshape(B, W, 16)[:, :, :NM] / p.n
+names = (["extract", "barrier1", "fwd+mac", "barrier2", "gather", "barrier3", "inv+store", "barrier4", "update", "barrier5"] if n2048 else
+         ["keys+dec", "forward", "mac+store", "barrier1", "gather", "inv+store", "barrier2", "update"] if oct_kernel else
          ["decompose", "forward", "mac+keys", "barrier1", "gather", "barrier2", "inverse", "update"])
-print("kernel ms", ck.ctx.last_kernel_ms(0), "eight-wave" if oct_kernel else "two-wave")
+print("kernel ms", ck.ctx.last_kernel_ms(0), "N=2048 four-wave" if n2048 else "eight-wave" if oct_kernel else "two-wave")
 print("wave  " + "".join(f"{n:>10s}" for n in names) + "     total")
 for w in range(W):
     row = t[0, w]
@@ -41,7 +45,7 @@ print("mean (std) over the launch's items:")
 for w in range(W):
     print(f"w{w}    " + "".join(f"{v:10.0f}" for v in m[w]) + f"{m[w].sum():10.0f}")
     print("      " + "".join(f"{'(%d)' % v:>10s}" for v in sd[w]))
-if not oct_kernel and B % 4 == 0:
+if not oct_kernel and not n2048 and B % 4 == 0:
     print("mean by position of the item in a four-item workgroup (launches of > 3 bootstraps per CU):")
     for pos in range(4):
         for w in range(W):
