@@ -201,8 +201,19 @@ def main():
         from go_tfhe_amd.distributed import broadcast_cloud_key
         ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank) if rank == 0 else pkg.CloudKey(p, device=local_rank)
         t0 = time.perf_counter()
-        broadcast_cloud_key(ck.ctx, src=0)
+        try:
+            broadcast_cloud_key(ck.ctx, src=0)
+            sent = 1
+        except Exception as e:                                   # keep the run alive: every rank holds the key material
+            print(f"[bench] rank {rank}: key broadcast failed ({e}); loading the key locally", file=sys.stderr)
+            sent = 0
         key_broadcast_ms = (time.perf_counter() - t0) * 1e3
+        agreed = torch.tensor([sent], device=dev, dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            ck.close()
+            ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank)
+            key_broadcast_ms = None
     else:
         ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank)
         key_broadcast_ms = None
