@@ -32,9 +32,10 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         const dim3 g(cnt);
         if (shape_is_1024(shape) && cnt <= quad_max) {
             // one workgroup per CU: one wave per SIMD, all key levels prefetched; two per CU: two waves per SIMD
-            if (cnt <= num_cus && cnt <= oct_limit && shape == kShapeN1024_L3_B6) {
-                // one bootstrap per CU on eight waves
-                hipLaunchKernelGGL((k_blind_rotate_oct<3, 6>), g, dim3(512), 0, st, a);
+            if (cnt <= num_cus && cnt <= oct_limit && shape != kShapeN1024_L1_B23) {
+                // one bootstrap per CU on eight waves (two or three gadget levels to split)
+                if (shape == kShapeN1024_L3_B6) hipLaunchKernelGGL((k_blind_rotate_oct<3, 6>), g, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((k_blind_rotate_oct<2, 10>), g, dim3(512), 0, st, a);
             } else if (cnt <= num_cus) {
                 switch (shape) {
                 case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 1>), g, dim3(256), 0, st, a); break;

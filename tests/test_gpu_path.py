@@ -326,7 +326,7 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
     ck4 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
     # ... and with the eight-wave kernel switched off (it serves L = 3 launches of at most one bootstrap per CU)
     monkeypatch.setenv("TFHE_OCT_MAX", "0")
-    ck4only = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk) if which == "small" else None
+    ck4only = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk) if which != "uint3" else None     # L = 1: no eight-wave form
     monkeypatch.delenv("TFHE_QUAD_MAX")
     monkeypatch.delenv("TFHE_OCT_MAX")
     rs = np.random.RandomState(21)
@@ -346,6 +346,10 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
                 tol = 2 * (2**4 if which == "uint1" else 2**12)
                 diff = (a.astype(np.int64) - b.astype(np.int64) + 2**31) % 2**32 - 2**31
                 assert np.abs(diff).max() <= tol, (which, B, nsteps, np.abs(diff).max())
+                if ck4only is not None:
+                    c = ck4only.ctx.blind_rotate_batch(cts, tvs, nsteps)
+                    diff = (a.astype(np.int64) - c.astype(np.int64) + 2**31) % 2**32 - 2**31
+                    assert np.abs(diff).max() <= tol, (which, B, nsteps, np.abs(diff).max())
     ck2.close(); ck4.close()
     if ck4only is not None:
         ck4only.close()
