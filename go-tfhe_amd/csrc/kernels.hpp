@@ -163,11 +163,14 @@ struct PhaseClock {
 #ifdef PHASE_TRACE
     long long sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prev = 0;
     __device__ __forceinline__ void start() { __builtin_amdgcn_sched_barrier(0); prev = clock64(); __builtin_amdgcn_sched_barrier(0); }
-    // PHASE_TRACE = 1 keeps only the marks around the first barrier of a step (2, 3: the wave has drained its LDS
-    // operations there anyway) and lumps everything else into mark 7: the timeline of an almost undisturbed kernel
+    // with -DPHASE_TRACE_LIGHT only the marks around the first barrier of a step of the two-wave kernel remain (2, 3:
+    // the wave has drained its LDS operations there anyway) and everything else is lumped into mark 7: the
+    // timeline of an almost undisturbed kernel
     __device__ __forceinline__ void mark(int k)
     {
-        if (PHASE_TRACE == 1 && k != 2 && k != 3 && k != 7) return;      // (two-wave N = 1024 kernel's numbering)
+#ifdef PHASE_TRACE_LIGHT
+        if (k != 2 && k != 3 && k != 7) return;
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const long long now = clock64();
         sum[k] += now - prev;
