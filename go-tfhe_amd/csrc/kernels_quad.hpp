@@ -548,7 +548,15 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
 
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#ifdef OCT_G0_OLD
     const int g = w >> 2, ph = w & 3, p = ph >> 1, h = ph & 1;
+    const int g0_wave = ph;
+#else
+    // group 1 (the longer chain: it also runs the inverse transform) takes waves 0-3: the older wave of a SIMD wins the
+    // issue arbiter (profiles/r02_f_phase_trace.txt)
+    const int g = 1 - (w >> 2), ph = w & 3, p = ph >> 1, h = ph & 1;
+    const int g0_wave = 4 + ph;
+#endif
     uint32_t *acc = accAll[w];
     cd *sc = scAll[w];
     const int item = A.first + blockIdx.x;
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
         if (g == 1) {
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                keep[k] = (keep[k] + scAll[ph][k * 64 + lane]) + (sendG[0][partner][k * 64 + lane] + sendG[1][partner][k * 64 + lane]);
+                keep[k] = (keep[k] + scAll[g0_wave][k * 64 + lane]) + (sendG[0][partner][k * 64 + lane] + sendG[1][partner][k * 64 + lane]);
             tr.mark(4);
             fft256_inverse(keep, sc, T, tw, q);
 #pragma unroll
