@@ -473,8 +473,8 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
 #define OCT_KEY_GAP 8
 #endif
 template <int L, int BGBIT, int LB, int NL>
-__device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint32_t *acc /* signed table */,
-                                            const uint32_t (&areg)[4][4], int at, double sr, int lane, int p,
+__device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint32_t *Tp /* signed table of polynomial p */,
+                                            int at, double sr, int lane, int p,
                                             const cd *__restrict__ key_iph /* &bskq[i][p][h][0] */, cd *sc,
                                             const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q, cd (&keep)[4],
                                             cd (&send)[4], PhaseClock &tr)
@@ -489,13 +489,14 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
     __builtin_amdgcn_sched_barrier(0);
 #endif
     cd x[NL][4];
-    const int base = lane - at;
+    // X^at * acc - acc straight from the signed table (T[s] = acc[s], ~acc[s - N], acc[s - 2N] for s in [0, N), [N, 2N),
+    // [2N, 3N)): two base addresses per step, every coefficient an immediate offset from them
+    const uint32_t *rot = Tp + ((lane - at) & (2 * N - 1)), *own = Tp + lane;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         uint32_t dd[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++)         // X^at * acc straight from the signed table: entry s >= N is ~acc[s - N]
-            dd[k] = acc[(base + 64 * a + 256 * k) & (2 * N - 1)] - areg[a][k] + A.offset;
+        for (int k = 0; k < 4; k++) dd[k] = rot[64 * a + 256 * k] - own[64 * a + 256 * k] + A.offset;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             const int shift = 32 - (LB + l + 1) * BGBIT;
@@ -541,23 +542,18 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
     __shared__ cd scAll[8][256];            // FFT exchanges; a group-0 wave also leaves its products for its own half here
     __shared__ cd sendG[2][4][256];         // products for the partner polynomial, by group
     __shared__ cd swapAll[4][256];          // inverse transform results, for the half swap
-    __shared__ uint32_t accAll[8][2 * N];   // per wave: the accumulator polynomial and its complement = the 2N-periodic
-                                            // signed table T[s] = (X^s-coefficient sign) so X^a*acc is a plain gather
+    __shared__ uint32_t accT[2][3 * N];     // per polynomial: the signed table of the accumulator, T[s] = acc[s], ~acc[s - N],
+                                            // acc[s - 2N]: coefficient j of X^a*acc is T[((-a) mod 2N) + j], no wrap, no sign fix
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
 
     const int lane = threadIdx.x & 63, tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#ifdef OCT_G0_OLD
-    const int g = w >> 2, ph = w & 3, p = ph >> 1, h = ph & 1;
-    const int g0_wave = ph;
-#else
     // group 1 (the longer chain: it also runs the inverse transform) takes waves 0-3: the older wave of a SIMD wins the
     // issue arbiter (profiles/r02_f_phase_trace.txt)
     const int g = 1 - (w >> 2), ph = w & 3, p = ph >> 1, h = ph & 1;
     const int g0_wave = 4 + ph;
-#endif
-    uint32_t *acc = accAll[w];
+    uint32_t *Tp = accT[p];
     cd *sc = scAll[w];
     const int item = A.first + blockIdx.x;
     if (!gate_item_live(A, item)) return;
@@ -567,29 +563,27 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
     load_quad_twiddles(tw, T, lane);
     const QuadLane q = quad_lane(lane);
     __syncthreads();
-    // the wave's copy of polynomial p: coefficient 64a + lane + 256k in areg[a][k], mirrored into the signed table
-    uint32_t areg[4][4];
+    // the four waves of polynomial p maintain its table together: wave (g, h) owns coefficients 64 qa + lane + 256 k
+    const int qa = 2 * g + h;
     {
         const int bt = btL & (2 * N - 1);
         const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int j = 64 * a + lane + 256 * k;
-                const int s = (j - bt) & (2 * N - 1);
-                uint32_t v = tv[s & (N - 1)];
-                v ^= 0u - (uint32_t)((s >> 10) & 1);
-                areg[a][k] = v;
-                acc[j] = v;
-                acc[j + N] = ~v;
-            }
+        for (int k = 0; k < 4; k++) {
+            const int j = 64 * qa + lane + 256 * k;
+            const int s = (j - bt) & (2 * N - 1);
+            uint32_t v = tv[s & (N - 1)];
+            v ^= 0u - (uint32_t)((s >> 10) & 1);       // "negation" is the bitwise complement (buffer_methods.go:152,158)
+            Tp[j] = v;
+            Tp[j + N] = ~v;
+            Tp[j + 2 * N] = v;
+        }
     }
-    wave_lds_order();
+    __syncthreads();
 
     constexpr size_t kStep = (size_t)2 * L * 2 * 512;
     const cd *key = A.bskq + ((size_t)p * 2 + h) * (L * 2 * 256);
-    const int partner = ph ^ 2, sibling = ph ^ 1;
+    const int partner = ph ^ 2;
     const double sr = h ? -r : r;
     constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;
     const int nsteps = A.nsteps;
@@ -599,14 +593,14 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         cd keep[4], send[4];
         if (g == 0) {
-            oct_forward<L, BGBIT, 0, L0>(A, acc, areg, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
+            oct_forward<L, BGBIT, 0, L0>(A, Tp, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sc[k * 64 + lane] = keep[k];
                 sendG[0][ph][k * 64 + lane] = send[k];
             }
         } else {
-            oct_forward<L, BGBIT, L0, L1>(A, acc, areg, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
+            oct_forward<L, BGBIT, L0, L1>(A, Tp, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
 #pragma unroll
             for (int k = 0; k < 4; k++) sendG[1][ph][k * 64 + lane] = send[k];
         }
@@ -625,24 +619,24 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
         }
         __syncthreads();
         tr.mark(6);
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            const cd own = swapAll[ph][a * 64 + lane], o = swapAll[sibling][a * 64 + lane];
-            const cd s = own + o, dl = own - o;
-            const double e1r = (dl.re + dl.im) * sr, e1i = (dl.im - dl.re) * sr;
-            areg[a][0] += kSmall ? round_to_torus_small(s.re) : round_to_torus_wide(s.re);
-            areg[a][2] += kSmall ? round_to_torus_small(s.im) : round_to_torus_wide(s.im);
-            areg[a][1] += kSmall ? round_to_torus_small(e1r) : round_to_torus_wide(e1r);
-            areg[a][3] += kSmall ? round_to_torus_small(e1i) : round_to_torus_wide(e1i);
+        // undo the radix-2 level for this wave's quarter: z_j = y0 + y1, z_{j+256} = conj(rho)(y0 - y1) (the 1/2 is in
+        // the inverse's scale), acc += round(.) (evaluator.go:102-105), written to all three copies of the table
+        {
+            const cd y0 = swapAll[2 * p][qa * 64 + lane], y1 = swapAll[2 * p + 1][qa * 64 + lane];
+            const cd s = y0 + y1, dl = y0 - y1;
+            const double z[4] = {s.re, (dl.re + dl.im) * r, s.im, (dl.im - dl.re) * r};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int j = 64 * a + lane + 256 * k;
-                acc[j] = areg[a][k];
-                acc[j + N] = ~areg[a][k];
+                const int j = 64 * qa + lane + 256 * k;
+                const uint32_t v = Tp[j] + (kSmall ? round_to_torus_small(z[k]) : round_to_torus_wide(z[k]));
+                Tp[j] = v;
+                Tp[j + N] = ~v;
+                Tp[j + 2 * N] = v;
             }
         }
-        wave_lds_order();
         tr.mark(7);
+        __syncthreads();
+        tr.mark(8);
     }
 #ifdef PHASE_TRACE
     tr.store(A.out + (size_t)item * 2 * N, w, lane);
@@ -650,11 +644,12 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
 #endif
 
     if (g == 0) {
+        // wave (p, h) stores coefficient blocks [256h, 256h+256) and [512+256h, 512+256h+256) of polynomial p
         uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
-        for (int a = 0; a < 4; a++) {
-            out[64 * a + lane + 256 * h] = areg[a][h];
-            out[64 * a + lane + 256 * h + 512] = areg[a][2 + h];
+        for (int k = 0; k < 8; k++) {
+            const int j = 64 * (k & 3) + lane + 256 * h + 512 * (k >> 2);
+            out[j] = Tp[j];
         }
     }
     report_bad_op(A, bad_op, tid);

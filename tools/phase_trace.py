@@ -5,7 +5,7 @@
 Prints shader-clock cycles per step between the marks of PhaseClock (kernels.hpp), per wave of item 0 and averaged over
 the launch.  Batches of <= one bootstrap per CU run the eight-wave kernel (kernels_quad.hpp; marks: 0 keys+decompose,
 1 forward transforms, 2 products+hand-over stores, 3 barrier 1, 4 gather (group 1), 5 inverse+store (group 1),
-6 barrier 2 (group 0: the whole wait), 7 update); larger ones the two-wave kernel (0 decompose, 1 forward transforms
+6 barrier 2 (group 0: the whole wait), 7 update, 8 barrier 3); larger ones the two-wave kernel (0 decompose, 1 forward transforms
 (+ level-0 key request), 2 products + key refills + hand-over stores, 3 barrier 1, 4 gather, 5 barrier 2,
 6 inverse+round, 7 accumulate)."""
 import argparse, os, sys
@@ -30,10 +30,10 @@ torch.cuda.synchronize()
 n2048 = p.N == 2048
 oct_kernel = not n2048 and B <= torch.cuda.get_device_properties(0).multi_processor_count
 W = 4 if n2048 else 8 if oct_kernel else 2
-NM = 10 if n2048 else 8
+NM = 10 if n2048 else 9 if oct_kernel else 8
 t = o.cpu().numpy().view(np.int64).reshape(B, -1)[:, :16 * W].reshape(B, W, 16)[:, :, :NM] / p.n
 names = (["extract", "barrier1", "fwd+mac", "barrier2", "gather", "barrier3", "inv+store", "barrier4", "update", "barrier5"] if n2048 else
-         ["keys+dec", "forward", "mac+store", "barrier1", "gather", "inv+store", "barrier2", "update"] if oct_kernel else
+         ["keys+dec", "forward", "mac+store", "barrier1", "gather", "inv+store", "barrier2", "update", "barrier3"] if oct_kernel else
          ["decompose", "forward", "mac+keys", "barrier1", "gather", "barrier2", "inverse", "update"])
 print("kernel ms", ck.ctx.last_kernel_ms(0), "N=2048 four-wave" if n2048 else "eight-wave" if oct_kernel else "two-wave")
 print("wave  " + "".join(f"{n:>10s}" for n in names) + "     total")
