@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1024)
+ap.add_argument("--groups", type=int, default=2, help="wave groups of the small-batch kernel in the traced build (OCT_GROUPS_L3)")
 ap.add_argument("--params", default="128", help="128 (N = 1024 kernels) or uint5 (the four-wave N = 2048 kernel)")
 args = ap.parse_args()
 pkg = g.load_package()
@@ -29,13 +30,13 @@ for _ in range(3): ck.ctx.blind_rotate_batch_dev(c, None, o)
 torch.cuda.synchronize()
 n2048 = p.N == 2048
 oct_kernel = not n2048 and B <= torch.cuda.get_device_properties(0).multi_processor_count
-W = 4 if n2048 else 8 if oct_kernel else 2
+W = 4 if n2048 else 4 * args.groups if oct_kernel else 2
 NM = 10 if n2048 else 9 if oct_kernel else 8
 t = o.cpu().numpy().view(np.int64).reshape(B, -1)[:, :16 * W].reshape(B, W, 16)[:, :, :NM] / p.n
 names = (["extract", "barrier1", "fwd+mac", "barrier2", "gather", "barrier3", "inv+store", "barrier4", "update", "barrier5"] if n2048 else
          ["keys+dec", "forward", "mac+store", "barrier1", "gather", "inv+store", "barrier2", "update", "barrier3"] if oct_kernel else
          ["decompose", "forward", "mac+keys", "barrier1", "gather", "barrier2", "inverse", "update"])
-print("kernel ms", ck.ctx.last_kernel_ms(0), "N=2048 four-wave" if n2048 else "eight-wave" if oct_kernel else "two-wave")
+print("kernel ms", ck.ctx.last_kernel_ms(0), "N=2048 four-wave" if n2048 else f"{4 * args.groups}-wave" if oct_kernel else "two-wave")
 print("wave  " + "".join(f"{n:>10s}" for n in names) + "     total")
 for w in range(W):
     row = t[0, w]
