@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
         }
 #pragma unroll
         for (int a = 0; a < 8; a++) {
-            accL[p][64 * a + lane + 512 * h] += e[a];
-            accL[p][64 * a + lane + 512 * h + 1024] += e[a + 8];
+            lds_add(&accL[p][64 * a + lane + 512 * h], e[a]);
+            lds_add(&accL[p][64 * a + lane + 512 * h + 1024], e[a + 8]);
         }
         clk.mark(8);
         __syncthreads();

@@ -243,8 +243,8 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate_512(BlindRotateArgs A)
         external_product_core_512<BGBIT>(coef, e, A.bsk + (size_t)i * 4 * 256, A.offset, sch, A.tw, tw, h, hl);
 #pragma unroll
         for (int a = 0; a < 8; a++) {
-            acc[32 * a + hl] += e[a];
-            acc[32 * a + hl + 256] += e[8 + a];
+            lds_add(&acc[32 * a + hl], e[a]);
+            lds_add(&acc[32 * a + hl + 256], e[8 + a]);
         }
         wave_lds_order();
     }

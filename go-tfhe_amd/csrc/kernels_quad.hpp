@@ -443,10 +443,10 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
             const cd s = keep[a] + o, dl = keep[a] - o;
             const double e1r = (dl.re + dl.im) * sr, e1i = (dl.im - dl.re) * sr;
             const int j = 64 * a + lane;
-            acc[j] += kSmall ? round_to_torus_small(s.re) : round_to_torus_wide(s.re);
-            acc[j + 512] += kSmall ? round_to_torus_small(s.im) : round_to_torus_wide(s.im);
-            acc[j + 256] += kSmall ? round_to_torus_small(e1r) : round_to_torus_wide(e1r);
-            acc[j + 768] += kSmall ? round_to_torus_small(e1i) : round_to_torus_wide(e1i);
+            lds_add(&acc[j], kSmall ? round_to_torus_small(s.re) : round_to_torus_wide(s.re));
+            lds_add(&acc[j + 512], kSmall ? round_to_torus_small(s.im) : round_to_torus_wide(s.im));
+            lds_add(&acc[j + 256], kSmall ? round_to_torus_small(e1r) : round_to_torus_wide(e1r));
+            lds_add(&acc[j + 768], kSmall ? round_to_torus_small(e1i) : round_to_torus_wide(e1i));
         }
         wave_lds_order();
     }
