@@ -470,11 +470,13 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
 
 // ---------------------------------------------------------------------------------------------------------
 // Eight waves per bootstrap (launches of at most one bootstrap per CU): the four (p, h) waves above, twice.
-// Group 0 transforms gadget levels [0, L0) and group 1 levels [L0, L) of the same (p, h) half-polynomial, so the
+// One group transforms gadget levels [0, L0), the other levels [L0, L) of the same (p, h) half-polynomial, so the
 // forward phase of a CMUX step is ceil(L/2) transforms deep instead of L and both waves of a SIMD issue side by
-// side.  Group 1 then gathers the four partial products of its output half (its own, group 0's, and the partner
-// polynomial's two), runs the one inverse transform and publishes the result; all eight waves apply the update to
-// their private copy of the accumulator.  Two barriers per step, as in the four-wave kernel.
+// side.  The group with fewer levels then gathers the four partial products of its output half (its own, the other
+// group's, and the partner polynomial's two), runs the one inverse transform and publishes the result.  The accumulator
+// is one signed table of 3N words per polynomial, T[s] = acc[s], ~acc[s - N], acc[s - 2N], shared by the polynomial's
+// four waves: the decomposition reads X^a*acc - acc through two base addresses and immediate offsets, each wave
+// updates its quarter of the coefficients after the half swap, and a third barrier publishes the table.
 #ifndef OCT_KEY_GAP
 #define OCT_KEY_GAP 8
 #endif
