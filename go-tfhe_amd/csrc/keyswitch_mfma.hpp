@@ -1,0 +1,203 @@
+// keyswitch_mfma.hpp -- the base-4 identity key switch (keyswitch.go:10-37) as an exact int8 matrix product.
+//
+// out[m] = (0, ..., 0, b_m) - sum_{i < N, j < t} KSK[(i t + j) 4 + d(m, i, j)], d = the j-th base-4 digit of the
+// i-th extracted coefficient.  Written over all four candidate rows of a digit (row k = 0 is all-zero,
+// keyswitch.go:30) that is  out = init - H x KSK  with H[m][K] in {0, 1} one-hot per digit, K = N t 4 = 36,864 at
+// the 128-bit set: 1,024 x 36,864 x 2,804 byte-columns per batch.  The 32-bit words of the key are split into their four
+// bytes, each byte column summed exactly by v_mfma_i32_32x32x32_i8 (at most N t = 9,216 terms of magnitude <= 128:
+// 21 bits), and the four column sums of a word recombined mod 2^32 -- bit-identical to the row-by-row subtraction.
+// The instruction multiplies SIGNED bytes, so the key copy holds u ^ 0x80 (= u - 128); every digit selects exactly
+// one row, so the correction is the constant 128 N t per byte column.
+//
+// Layouts (both operands are stored as the instruction's lanes read them: one 16-byte piece = 16 consecutive K of
+// one row / column):
+//   K order   K = (j N + i) 4 + k: piece kb = j N/4 + i/4 holds coefficients 4 (i/4) .. +3 of digit level j
+//   kskB      int8 [t N / 4][colsP][16]   colsP = 4 (n + 1) rounded up to 256; built once per key (k_ksk_mfma_pack)
+//   H         int8 [t N / 4][Mpad][16]    Mpad = ciphertexts rounded up to 256; built per launch (k_ks_onehot):
+//                                         a digit is the 32-bit word 1 << 8 d
+// One wave = one 128 x 128 tile of (ciphertexts x byte columns) over a range of K: 4 + 4 operand pieces of 16 bytes per
+// lane feed 16 MFMAs; partial sums over the K ranges are combined with 32-bit atomics into `out`, which k_ks_init has
+// set to (0, ..., 0, b).  Lane layout of the instruction: tools/probe_mfma_i8.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfhe {
+
+typedef int ks_v4i __attribute__((ext_vector_type(4)));
+typedef int ks_v16i __attribute__((ext_vector_type(16)));
+
+
+// packed key [N][t][3][n1p] (k = 1..3; kernels.hpp) -> kskB
+static __global__ void k_ksk_mfma_pack(const uint32_t *__restrict__ packed, uint4 *__restrict__ dst, int N, int t, int n1,
+                                       int n1p, int colsP)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)t * (N / 4) * colsP;
+    if (idx >= total) return;
+    const int col = (int)(idx % colsP), kb = (int)(idx / colsP);
+    const int j = kb / (N / 4), i0 = 4 * (kb % (N / 4));
+    uint32_t w[4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ii++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t u = 0;
+            if (k > 0 && col < 4 * n1) {
+                const uint32_t word = packed[((size_t)((i0 + ii) * t + j) * 3 + (k - 1)) * n1p + (col >> 2)];
+                u = (word >> (8 * (col & 3))) & 0xFFu;
+            }
+            v |= (u ^ 0x80u) << (8 * k);
+        }
+        w[ii] = v;
+    }
+    dst[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Sample extract at index 0 (trlwe_ops.go:13-19) + digit decomposition (keyswitch.go:14-16,25-29) -> H.
+// Workgroup = 16 ciphertexts x 16 coefficient quads; stores of one digit level are 256 contiguous bytes per quad.
+static __global__ __launch_bounds__(256) void k_ks_onehot(const uint32_t *__restrict__ trlwe, uint4 *__restrict__ H, int N, int t,
+                                                          int M, int Mpad, const int *__restrict__ count, int m_base)
+{
+    const int tid = threadIdx.x, m = 16 * blockIdx.x + (tid & 15), iq = 16 * blockIdx.y + (tid >> 4);
+    int live_items = M;
+    if (count) { const int c = *count - m_base; live_items = c < M ? (c < 0 ? 0 : c) : M; }
+    const bool live = m < live_items;
+    const uint32_t prec = 1u << (32 - (1 + 2 * t));
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (live) {
+        const uint32_t *ta = trlwe + (size_t)m * 2 * N;
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            const int i = 4 * iq + ii;
+            const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
+            w[ii] = (ai + prec) >> (32 - 2 * t);              // t digits, most significant first
+        }
+    }
+    for (int j = 0; j < t; j++) {
+        const int sh = 2 * (t - 1 - j);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (live) v = make_uint4(1u << (8 * ((w[0] >> sh) & 3)), 1u << (8 * ((w[1] >> sh) & 3)), 1u << (8 * ((w[2] >> sh) & 3)),
+                                 1u << (8 * ((w[3] >> sh) & 3)));
+        H[((size_t)j * (N / 4) + iq) * Mpad + m] = v;
+    }
+}
+
+// One workgroup = four waves = a 256 x 256 tile of (ciphertexts x byte columns) over a range of K, wave (wm, wn) owning
+// the 128 x 128 quarter.  K advances in stages of kKsStage chunks of 32.  Every thread moves one 16-byte piece of H and
+// one of kskB per K piece: global memory -> registers three stages ahead (two register sets, alternating), registers
+// -> the other LDS buffer one stage ahead, one barrier per stage; each operand piece crosses L2 -> CU once per
+// workgroup and is read from LDS by the two waves that need it.  Register budget: 256 accumulators + 2 x 16 staging
+// + 32 operands: one wave per SIMD, one workgroup per CU -- so the launch is sized to at most one workgroup per CU
+// (K ranges of uneven length), never a second partial round.
+constexpr int kKsStage = 2;                  // chunks of 32 K per stage: 2 x 32 KB of LDS
+constexpr int kKsGroup = 256;                // workgroup tile edge
+
+__global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint4 *__restrict__ H, const uint4 *__restrict__ kskB,
+                                                        uint32_t *__restrict__ out, int Mpad, int colsP, int n1, int M,
+                                                        const int *__restrict__ count, int m_base, int m_groups, int n_groups,
+                                                        int pairs_total, int pairs_per_part, uint32_t bias_word)
+{
+    constexpr int P = 2 * kKsStage;          // 16-K pieces per stage
+    __shared__ uint4 ldsA[2][P][kKsGroup], ldsB[2][P][kKsGroup];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+#ifdef KS_XCD_PARTS
+    const int kp = blockIdx.x % KS_XCD_PARTS, tile_ = blockIdx.x / KS_XCD_PARTS, ng = tile_ % n_groups, mg = tile_ / n_groups;
+#else
+    const int ng = blockIdx.x % n_groups, mg = (blockIdx.x / n_groups) % m_groups, kp = blockIdx.x / (n_groups * m_groups);
+#endif
+    const int m0 = mg * kKsGroup, n0 = ng * kKsGroup;
+    int live_items = M;
+    if (count) { const int c = *count - m_base; live_items = c < M ? (c < 0 ? 0 : c) : M; }
+    if (m0 >= live_items) return;
+    const bool rows_live = m0 + wm * 128 < live_items;          // (a wave whose 128 rows are all padding multiplies zeros)
+    const int pair0 = kp * pairs_per_part;
+    const int pairs = pairs_total - pair0 < pairs_per_part ? pairs_total - pair0 : pairs_per_part;     // stage pairs of this range
+    const int stages = 2 * pairs;
+    const size_t kb0 = (size_t)pair0 * 2 * P;
+    const uint4 *gA = H + kb0 * Mpad + m0 + tid;
+    const uint4 *gB = kskB + kb0 * colsP + n0 + tid;
+    const size_t stepA = (size_t)P * Mpad, stepB = (size_t)P * colsP;
+
+    ks_v16i acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mi][ni][r] = 0;
+
+    // stage index -> its pieces (clamped to the range: the tail re-reads the last stage, never used).  Macros over
+    // named registers, not lambdas over arrays: those end up in scratch memory.
+    static_assert(P == 4, "the staging registers below are written out for two chunks per stage");
+#define KS_FETCH(st, R)                                                                                   \
+    {                                                                                                     \
+        const int sc_ = (st) < stages ? (st) : stages - 1;                                                \
+        const uint4 *pa_ = gA + (size_t)sc_ * stepA, *pb_ = gB + (size_t)sc_ * stepB;                     \
+        R##a0 = pa_[0]; R##a1 = pa_[(size_t)Mpad]; R##a2 = pa_[(size_t)2 * Mpad]; R##a3 = pa_[(size_t)3 * Mpad];         \
+        R##b0 = pb_[0]; R##b1 = pb_[(size_t)colsP]; R##b2 = pb_[(size_t)2 * colsP]; R##b3 = pb_[(size_t)3 * colsP];     \
+    }
+#define KS_STASH(buf, R)                                                                                  \
+    {                                                                                                     \
+        ldsA[buf][0][tid] = R##a0; ldsA[buf][1][tid] = R##a1; ldsA[buf][2][tid] = R##a2; ldsA[buf][3][tid] = R##a3;     \
+        ldsB[buf][0][tid] = R##b0; ldsB[buf][1][tid] = R##b1; ldsB[buf][2][tid] = R##b2; ldsB[buf][3][tid] = R##b3;     \
+    }
+#define KS_MULTIPLY(buf)                                                                                  \
+    _Pragma("unroll") for (int ch = 0; ch < kKsStage; ch++) {                                             \
+        ks_v4i a[4], b[4];                                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                   \
+            __builtin_memcpy(&a[q], &ldsA[buf][2 * ch + (l >> 5)][wm * 128 + 32 * q + (l & 31)], 16);    \
+            __builtin_memcpy(&b[q], &ldsB[buf][2 * ch + (l >> 5)][wn * 128 + 32 * q + (l & 31)], 16);    \
+        }                                                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 4; mi++)                                                  \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ni++)                                              \
+                acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);  \
+    }
+
+    uint4 xa0, xa1, xa2, xa3, xb0, xb1, xb2, xb3, ya0, ya1, ya2, ya3, yb0, yb1, yb2, yb3;
+    KS_FETCH(0, x);
+    KS_STASH(0, x);
+    KS_FETCH(1, x);             // set x: stage s + 1 at the top of an even stage s
+    KS_FETCH(2, y);             // set y: stage s + 2
+    __syncthreads();
+    for (int s = 0; s < stages; s += 2) {
+        KS_MULTIPLY(0);
+        KS_STASH(1, x);
+        KS_FETCH(s + 3, x);
+        __syncthreads();
+        KS_MULTIPLY(1);
+        KS_STASH(0, y);
+        KS_FETCH(s + 4, y);
+        __syncthreads();
+    }
+#undef KS_FETCH
+#undef KS_STASH
+#undef KS_MULTIPLY
+    if (!rows_live) return;
+
+    // D[row (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col l & 31]: the four byte columns of an output word sit in four
+    // adjacent lanes; shift each to its place, add across the quad, lane 0 of the quad subtracts from `out`
+    const uint32_t fix = kp == 0 ? bias_word : 0u;
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) {
+            const int word = ((n0 + wn * 128 + 32 * ni) >> 2) + ((l & 31) >> 2);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint32_t v = (uint32_t)acc[mi][ni][r] << (8 * (l & 3));
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+                v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+                const int row = m0 + wm * 128 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+#ifdef KS_ABL_STORE
+                if ((l & 3) == 0 && word < n1 && row < live_items) out[(size_t)row * n1 + word] = 0u - (v + fix);
+#else
+                if ((l & 3) == 0 && word < n1 && row < live_items) atomicAdd(&out[(size_t)row * n1 + word], 0u - (v + fix));
+#endif
+            }
+        }
+}
+
+} // namespace tfhe

@@ -21,6 +21,7 @@
 #include "kernels_n2048.hpp"
 #include "kernels_n512.hpp"
 #include "kernels_quad.hpp"
+#include "keyswitch_mfma.hpp"
 #include "launch_blind_rotate.hpp"
 #include "keygen.hpp"
 
@@ -98,6 +99,9 @@ struct tfhe_ctx {
     std::vector<hipEvent_t> ev_pool;
     DevBuf bsk, ksk, tw, gate_tv;
     DevBuf status;              // one int: kStatus* bits set by kernels (bad op codes on the _dev path)
+    DevBuf kskB;                // byte-column copy of the key-switching key for the MFMA form (keyswitch_mfma.hpp; base-4 sets)
+    DevBuf s_onehot;            // its per-launch one-hot digit matrix
+    int ks_mfma_min = 0;        // batches of at least this many ciphertexts use it
     DevBuf bskq, twq;           // four-wave layout of the key + its twiddles (N = 1024 shapes, kernels_quad.hpp)
     bool have_bsk = false, have_ksk = false;
     // staging (grow-only)
@@ -247,6 +251,24 @@ int make_quad_key(tfhe_ctx *c, hipStream_t st)
     return TFHE_OK;
 }
 
+// Byte-column copy of the packed key-switching key for k_keyswitch_mfma (base-4 sets; keyswitch_mfma.hpp).
+constexpr int kKsMfmaMinDefault = 1;        // it wins from one ciphertext on (0.09 vs 0.27 ms; 0.135 vs 0.51 ms at 1,024)
+constexpr int kKsMfmaChunk = 1024;           // ciphertexts per one-hot matrix (38 MB at the 128-bit set)
+bool ks_mfma_shape(const tfhe_params &P) { return P.basebit == 2 && P.N % 64 == 0 && 1 + 2 * P.t <= 32 && (P.t * P.N / 8) % (2 * kKsStage) == 0; }
+int ks_mfma_cols(const tfhe_params &P) { return (4 * (P.n + 1) + kKsGroup - 1) / kKsGroup * kKsGroup; }
+int make_mfma_ksk(tfhe_ctx *c, hipStream_t st)
+{
+    if (!ks_mfma_shape(c->P) || c->ks_mfma_min <= 0) return TFHE_OK;
+    const int colsP = ks_mfma_cols(c->P);
+    const size_t pieces = (size_t)c->P.t * (c->P.N / 4) * colsP;
+    int rc;
+    if ((rc = c->kskB.reserve(pieces * sizeof(uint4)))) return rc;
+    hipLaunchKernelGGL(k_ksk_mfma_pack, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, c->ksk.as<uint32_t>(),
+                       c->kskB.as<uint4>(), c->P.N, c->P.t, c->P.n + 1, c->n1p, colsP);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+
 // Items of one blind-rotate request (see BlindRotateArgs): direct operands, or the list form of the MUX passes.
 struct RotateJob {
     const uint32_t *in0 = nullptr, *in1 = nullptr;
@@ -302,6 +324,38 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
+    // base-4 sets, batches: the exact int8 matrix-core form (keyswitch_mfma.hpp), in chunks of kKsMfmaChunk ciphertexts
+    if (c->kskB.p && c->ks_mfma_min > 0 && B >= c->ks_mfma_min) {
+        const int N = c->P.N, t = c->P.t, n1 = c->P.n + 1, colsP = ks_mfma_cols(c->P);
+        const int Bc = B < kKsMfmaChunk ? B : kKsMfmaChunk;
+        const int MpadMax = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
+        int rc;
+        if ((rc = c->s_onehot.reserve((size_t)t * (N / 4) * MpadMax * sizeof(uint4)))) return rc;
+        const size_t tot = (size_t)B * n1;
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, N, B, d_count);
+        const uint32_t bias_word = (uint32_t)((unsigned long long)(128ull * N * t) * 0x01010101ull);
+        const int pairs_total = t * N / 8 / (2 * kKsStage), n_groups = colsP / kKsGroup;
+        for (int m_base = 0; m_base < B; m_base += kKsMfmaChunk) {
+            const int M = B - m_base < kKsMfmaChunk ? B - m_base : kKsMfmaChunk;
+            const int Mpad = (M + kKsGroup - 1) / kKsGroup * kKsGroup, m_groups = Mpad / kKsGroup;
+            // K ranges: as many as give every CU at most ONE workgroup (that is all a CU holds: no second, partial round)
+            int parts = c->num_cus / (m_groups * n_groups);
+#ifdef KS_XCD_PARTS
+            parts = KS_XCD_PARTS;
+#endif
+            if (parts < 1) parts = 1;
+            if (parts > pairs_total) parts = pairs_total;
+            const int per_part = (pairs_total + parts - 1) / parts;
+            parts = (pairs_total + per_part - 1) / per_part;
+            hipLaunchKernelGGL(k_ks_onehot, dim3(Mpad / 16, N / 64), dim3(256), 0, st, d_trlwe + (size_t)m_base * 2 * N,
+                               c->s_onehot.as<uint4>(), N, t, M, Mpad, d_count, m_base);
+            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned)(m_groups * n_groups * parts)), dim3(256), 0, st,
+                               c->s_onehot.as<uint4>(), c->kskB.as<uint4>(), d_out + (size_t)m_base * n1, Mpad, colsP, n1, M, d_count,
+                               m_base, m_groups, n_groups, pairs_total, per_part, bias_word);
+        }
+        HIP_TRY(hipGetLastError());
+        return timing_end(c, 1, st, stop);
+    }
     // base-4 sets (80/110/128-bit): tiles of 32 ciphertexts x 256 columns, two (i, j) steps per LDS read
     constexpr int kT = 32;
     if (c->P.basebit == 2 && B >= kT && c->P.N % 16 == 0) {
@@ -603,6 +657,8 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
         c->quad_limit = e ? atoi(e) : c->num_cus;
         e = getenv("TFHE_OCT_MAX");
         c->oct_limit = e ? atoi(e) : c->num_cus;
+        e = getenv("TFHE_KS_MFMA_MIN");             // 0 = never (the vector-ALU key-switch kernels for every batch)
+        c->ks_mfma_min = e ? atoi(e) : kKsMfmaMinDefault;
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
@@ -743,6 +799,7 @@ int tfhe_load_ksk(tfhe_ctx *c, const uint32_t *ksk)
     hipLaunchKernelGGL(k_ksk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, raw.as<uint32_t>(),
                        c->ksk.as<uint32_t>(), n1, c->n1p, base, rows_p);
     HIP_TRY(hipGetLastError());
+    if ((rc = make_mfma_ksk(c, c->stream))) { raw.release(); return rc; }
     HIP_TRY(hipStreamSynchronize(c->stream));
     raw.release();
     c->have_ksk = true;
@@ -802,7 +859,7 @@ int tfhe_keygen_cloud_seeded(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1
     hipLaunchKernelGGL(k_keygen_ksk, dim3((unsigned)rows_p), dim3(64), 0, st, c->ksk.as<uint32_t>(), d_s0.as<uint32_t>(),
                        d_s1.as<uint32_t>(), P.n, c->n1p, P.t, P.basebit, rows_p, alpha_lv0, Seed128{seed.lo ^ 0x9E3779B97F4A7C15ull, seed.hi});
     HIP_TRY(hipGetLastError());
-    if ((rc = make_quad_key(c, st))) { d_s0.release(); d_s1.release(); d_spec.release(); return rc; }
+    if ((rc = make_quad_key(c, st)) || (rc = make_mfma_ksk(c, st))) { d_s0.release(); d_s1.release(); d_spec.release(); return rc; }
     HIP_TRY(hipStreamSynchronize(st));
     d_s0.release(); d_s1.release(); d_spec.release();
     c->have_bsk = c->have_ksk = true;
@@ -851,6 +908,7 @@ int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, void *stream)
     } else {
         if ((rc = c->ksk.reserve(bytes))) return rc;
         HIP_TRY(hipMemcpyAsync(c->ksk.p, d_src, bytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = make_mfma_ksk(c, st))) return rc;
         c->have_ksk = true;
     }
     return TFHE_OK;
@@ -882,7 +940,7 @@ int tfhe_key_import(tfhe_ctx *c, int which, const void *src)
     DevBuf &dstbuf = which == 0 ? c->bsk : c->ksk;
     if ((rc = dstbuf.reserve(bytes))) return rc;
     HIP_TRY(hipMemcpyAsync(dstbuf.p, src, bytes, hipMemcpyHostToDevice, c->stream));
-    if (which == 0 && (rc = make_quad_key(c, c->stream))) return rc;
+    if ((rc = which == 0 ? make_quad_key(c, c->stream) : make_mfma_ksk(c, c->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     (which == 0 ? c->have_bsk : c->have_ksk) = true;
     return TFHE_OK;

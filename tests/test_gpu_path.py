@@ -105,6 +105,29 @@ def test_extract_keyswitch_tiled_kernel_bit_exact(oracle, request, which, B):
         assert np.array_equal(got[b], want), b
 
 
+@pytest.mark.parametrize("which", ["small", "80", "128"])
+def test_matrix_core_keyswitch_equals_vector_kernels(pkg, oracle, request, which, monkeypatch):
+    # csrc/keyswitch_mfma.hpp (the default for the base-4 sets: exact int8 matrix product over byte columns) against the
+    # vector-ALU kernels of csrc/kernels.hpp (TFHE_KS_MFMA_MIN=0: per-ciphertext gather below 32, the tiled kernel above)
+    # on the same key and inputs, bit for bit, across the tile edges (256-row groups, 1,024-row chunks) -- and both
+    # against the oracle on a sample.
+    k = request.getfixturevalue({"small": "keys_small", "80": "keys80", "128": "keys128"}[which])
+    monkeypatch.setenv("TFHE_KS_MFMA_MIN", "0")
+    ckv = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
+    monkeypatch.delenv("TFHE_KS_MFMA_MIN")
+    ckm = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
+    rs = np.random.RandomState(23)
+    for B in ((1, 5, 33, 256, 257, 1025, 2100) if which == "small" else (1, 33, 300)):
+        trl = rand_u32(rs, (B, 2, 1024))
+        trl[0] = 0
+        trl[B // 2] = 0xFFFFFFFF
+        a, b = ckv.ctx.extract_keyswitch_batch(trl), ckm.ctx.extract_keyswitch_batch(trl)
+        assert np.array_equal(a, b), (which, B)
+        for i in sorted({0, B // 2, B - 1}):
+            assert np.array_equal(b[i], oracle.key_switch(k.p, k.ksk, oracle.sample_extract(trl[i]))), (which, B, i)
+    ckv.close(); ckm.close()
+
+
 def test_bootstrap_80bit_bit_exact_and_decrypts(oracle, keys80, ck80):
     k = keys80
     bits = [0, 1, 1]
