@@ -23,6 +23,10 @@ def _stale():
 
 def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into lib/libtfhe_hip.so (no-op when up to date)."""
+    if os.environ.get("TFHE_HIP_LIB") and os.path.exists(LIB_PATH):
+        # an experiment's own binary (tools/build_variant*.sh): never rebuilt from the current sources behind its back
+        print(f"[build] using TFHE_HIP_LIB={LIB_PATH} as it is", file=sys.stderr)
+        return LIB_PATH
     if not force and not _stale():
         print(f"[build] {os.path.relpath(LIB_PATH)}: up to date with csrc/ (reused)", file=sys.stderr)
         return LIB_PATH
