@@ -321,16 +321,18 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     a.n = c->P.n; a.N = c->P.N; a.t = c->P.t; a.basebit = c->P.basebit; a.n1p = c->n1p;
     a.count = d_count;
     const int ch = (c->n1p + 255) / 256;
+    const bool mfma = c->kskB.p && c->ks_mfma_min > 0 && B >= c->ks_mfma_min;
+    if (mfma) {                 // the one-hot matrix of one chunk (a no-op after reserve_scratch / the first call)
+        const int Bc = B < kKsMfmaChunk ? B : kKsMfmaChunk, MpadMax = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
+        int rc = c->s_onehot.reserve((size_t)c->P.t * (c->P.N / 4) * MpadMax * sizeof(uint4));
+        if (rc) return rc;
+    }
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
     // base-4 sets, batches: the exact int8 matrix-core form (keyswitch_mfma.hpp), in chunks of kKsMfmaChunk ciphertexts
-    if (c->kskB.p && c->ks_mfma_min > 0 && B >= c->ks_mfma_min) {
+    if (mfma) {
         const int N = c->P.N, t = c->P.t, n1 = c->P.n + 1, colsP = ks_mfma_cols(c->P);
-        const int Bc = B < kKsMfmaChunk ? B : kKsMfmaChunk;
-        const int MpadMax = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
-        int rc;
-        if ((rc = c->s_onehot.reserve((size_t)t * (N / 4) * MpadMax * sizeof(uint4)))) return rc;
         const size_t tot = (size_t)B * n1;
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, N, B, d_count);
         const uint32_t bias_word = (uint32_t)((unsigned long long)(128ull * N * t) * 0x01010101ull);
@@ -421,6 +423,10 @@ int reserve_scratch(tfhe_ctx *c, int items, bool mux)
     const size_t trl = (size_t)S * 2 * c->P.N * sizeof(uint32_t), rows = (size_t)S * (c->P.n + 1) * sizeof(uint32_t);
     int rc;
     if ((rc = c->s_trlwe.reserve(mux ? 2 * trl : trl))) return rc;
+    if (c->kskB.p) {            // one-hot digit matrix of the matrix-core key switch (one chunk; launch_keyswitch)
+        const int Bc = S < kKsMfmaChunk ? S : kKsMfmaChunk, Mpad = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
+        if ((rc = c->s_onehot.reserve((size_t)c->P.t * (c->P.N / 4) * Mpad * sizeof(uint4)))) return rc;
+    }
     if (mux) {
         const int nb = (S + kPlanBlock - 1) / kPlanBlock;
         if ((rc = c->s_idx.reserve((size_t)S * sizeof(int))) || (rc = c->s_plan.reserve((size_t)(2 * nb + 2) * sizeof(int))) ||
