@@ -298,7 +298,9 @@ def main():
                                  "the FFT exchanges (DESIGN.md section 3, PMC analysis)"},
             "verification": {"all_1024_decrypt_to_NAND": dec_ok, "sampled_outputs_bit_identical_to_oracle": bit_ok,
                              "sample": sample, "of": "the output buffer the last timed step wrote (zeroed before the timed region)"},
-            "kernels": {"k_blind_rotate_ms": br_avg_ms, "k_extract_keyswitch_ms": ks_avg_ms,
+            "kernels": {"k_blind_rotate_ms": br_avg_ms, "keyswitch_ms": ks_avg_ms,
+                        "keyswitch_kernels": "k_ks_init + k_ks_onehot + k_keyswitch_mfma (exact int8 matrix-core product, csrc/keyswitch_mfma.hpp)",
+                        "keyswitch_int8_Tops": 2.0 * BATCH * 4 * (p.n + 1) * (p.N * p.t * 4) / (ks_avg_ms * 1e-3) / 1e12 if ks_n else None,
                         "keyswitch_algorithmic_GBps": ks_alg / (ks_avg_ms * 1e-3) / 1e9 if ks_n else None},
         }
         if key_broadcast_ms is not None:
