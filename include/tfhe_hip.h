@@ -104,7 +104,9 @@ int tfhe_load_bsk_fourier(tfhe_ctx *ctx, const double *bsk);
  * trgsw.go:14-30); the engine runs its own forward FFT (trgsw.go:71-82). */
 int tfhe_load_bsk_torus(tfhe_ctx *ctx, const uint32_t *bsk);
 /* CloudKey.KeySwitchingKey (cloudkey.go:88-120): [N*t*base][n+1] uint32, flat index
- * base*t*i + base*j + k (keyswitch.go:29). */
+ * base*t*i + base*j + k (keyswitch.go:29).  On the device: the packed rows (the all-zero
+ * k = 0 rows dropped) and, for the base-4 sets, a second copy split into byte columns for
+ * the matrix-core key switch (78 MB + 104 MB at the 128-bit set). */
 int tfhe_load_ksk(tfhe_ctx *ctx, const uint32_t *ksk);
 
 /* cloudkey.NewCloudKey(secretKey) (cloudkey.go:24-31) on the GPU: genBootstrappingKey
