@@ -64,24 +64,22 @@ static __global__ __launch_bounds__(256) void k_ks_onehot(const uint32_t *__rest
     const int tid = threadIdx.x, m = 16 * blockIdx.x + (tid & 15), iq = 16 * blockIdx.y + (tid >> 4);
     int live_items = M;
     if (count) { const int c = *count - m_base; live_items = c < M ? (c < 0 ? 0 : c) : M; }
-    const bool live = m < live_items;
+    // rows past the live items stay as they are: the rows of a matrix product are independent and k_keyswitch_mfma
+    // never stores theirs
+    if (m >= live_items) return;
     const uint32_t prec = 1u << (32 - (1 + 2 * t));
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (live) {
-        const uint32_t *ta = trlwe + (size_t)m * 2 * N;
+    uint32_t w[4];
+    const uint32_t *ta = trlwe + (size_t)m * 2 * N;
 #pragma unroll
-        for (int ii = 0; ii < 4; ii++) {
-            const int i = 4 * iq + ii;
-            const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
-            w[ii] = (ai + prec) >> (32 - 2 * t);              // t digits, most significant first
-        }
+    for (int ii = 0; ii < 4; ii++) {
+        const int i = 4 * iq + ii;
+        const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
+        w[ii] = (ai + prec) >> (32 - 2 * t);                  // t digits, most significant first
     }
     for (int j = 0; j < t; j++) {
         const int sh = 2 * (t - 1 - j);
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (live) v = make_uint4(1u << (8 * ((w[0] >> sh) & 3)), 1u << (8 * ((w[1] >> sh) & 3)), 1u << (8 * ((w[2] >> sh) & 3)),
-                                 1u << (8 * ((w[3] >> sh) & 3)));
-        H[((size_t)j * (N / 4) + iq) * Mpad + m] = v;
+        H[((size_t)j * (N / 4) + iq) * Mpad + m] = make_uint4(1u << (8 * ((w[0] >> sh) & 3)), 1u << (8 * ((w[1] >> sh) & 3)),
+                                                              1u << (8 * ((w[2] >> sh) & 3)), 1u << (8 * ((w[3] >> sh) & 3)));
     }
 }
 
