@@ -130,11 +130,16 @@ __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint4 *__restrict_
     // stage index -> its pieces (clamped to the range: the tail re-reads the last stage, never used).  Macros over
     // named registers, not lambdas over arrays: those end up in scratch memory.
     static_assert(P == 4, "the staging registers below are written out for two chunks per stage");
+#ifdef KS_ABL_NOH               /* timing ablation: H not read (wrong results) */
+#define KS_LOAD_A(R) R##a0 = R##a1 = R##a2 = R##a3 = make_uint4(tid, 1, 2, 3); (void)pa_;
+#else
+#define KS_LOAD_A(R) R##a0 = pa_[0]; R##a1 = pa_[(size_t)Mpad]; R##a2 = pa_[(size_t)2 * Mpad]; R##a3 = pa_[(size_t)3 * Mpad];
+#endif
 #define KS_FETCH(st, R)                                                                                   \
     {                                                                                                     \
         const int sc_ = (st) < stages ? (st) : stages - 1;                                                \
         const uint4 *pa_ = gA + (size_t)sc_ * stepA, *pb_ = gB + (size_t)sc_ * stepB;                     \
-        R##a0 = pa_[0]; R##a1 = pa_[(size_t)Mpad]; R##a2 = pa_[(size_t)2 * Mpad]; R##a3 = pa_[(size_t)3 * Mpad];         \
+        KS_LOAD_A(R)                                                                                      \
         R##b0 = pb_[0]; R##b1 = pb_[(size_t)colsP]; R##b2 = pb_[(size_t)2 * colsP]; R##b3 = pb_[(size_t)3 * colsP];     \
     }
 #define KS_STASH(buf, R)                                                                                  \
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(256) void k_keyswitch_mfma(const uint4 *__restrict_
         __syncthreads();
     }
 #undef KS_FETCH
+#undef KS_LOAD_A
 #undef KS_STASH
 #undef KS_MULTIPLY
     if (!rows_live) return;
