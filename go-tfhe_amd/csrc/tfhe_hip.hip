@@ -351,9 +351,10 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
             parts = (pairs_total + per_part - 1) / per_part;
             hipLaunchKernelGGL(k_ks_onehot, dim3(Mpad / 16, N / 64), dim3(256), 0, st, d_trlwe + (size_t)m_base * 2 * N,
                                c->s_onehot.as<uint4>(), N, t, M, Mpad, d_count, m_base);
-            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned)(m_groups * n_groups * parts)), dim3(256), 0, st,
+            const int work = m_groups * n_groups * parts, grid = (work + 7) / 8 * 8;      // a multiple of the 8 XCDs (see the kernel)
+            hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned)grid), dim3(512), 0, st,
                                c->s_onehot.as<uint4>(), c->kskB.as<uint4>(), d_out + (size_t)m_base * n1, Mpad, colsP, n1, M, d_count,
-                               m_base, m_groups, n_groups, pairs_total, per_part, bias_word);
+                               m_base, m_groups, n_groups, pairs_total, per_part, parts, bias_word);
         }
         HIP_TRY(hipGetLastError());
         return timing_end(c, 1, st, stop);
