@@ -85,6 +85,27 @@ def test_balance_levels_keeps_depth_and_dependencies():
     assert max(len(l) for l in lv8) <= 4
 
 
+def test_schedule_min_cost_is_valid_and_no_worse():
+    # the cost-aware re-levelling (go-tfhe_amd/circuits.py): same gates, dependencies respected, critical path kept,
+    # and by its own cost model never worse than the balanced schedule it starts from
+    import __graft_entry__ as graft
+    graft.load_package()
+    from go_tfhe_amd.circuits import ripple_carry_adder, balance_levels, schedule_min_cost, launch_cost_ms
+    assert [launch_cost_ms(b) for b in (1, 256, 257, 1024, 1025)] == [2.75, 2.75, 4.17, 6.04, 6.04 + 2.75]
+    for bits, fold, inst in ((8, False, 256), (8, True, 256), (4, False, 32), (16, True, 100)):
+        levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=fold)
+        got = schedule_min_cost(levels, inst)
+        assert len(got) == len(levels)
+        assert sorted(g for l in got for g in l) == sorted(g for l in levels for g in l)
+        have = set(range(2 * bits)) | {3 * bits + 1}                     # inputs + the constant-false wire
+        for lvl in got:
+            for (op, x, y, z, out) in lvl:
+                assert x in have and y in have and (z is None or z in have)
+            have |= {g[4] for g in lvl}
+        cost = lambda lv: sum(launch_cost_ms(len(l) * inst) for l in lv)
+        assert cost(got) <= cost(balance_levels(levels, max(1, 1024 // inst))) + 1e-9
+
+
 # ---- host mirror of the reference's lut package (go-tfhe_amd/lut.py) -------------------------------
 
 def _lut_mod():

@@ -100,6 +100,14 @@ def test_adder_8bit_x256_128bit(oracle, keys128, ck128, pkg):
     CircuitExecutor(ck128.ctx, bal, n_wires).run(wt2)
     torch.cuda.synchronize()
     assert torch.equal(wt2, wt)
+    # ... and so does the cost-aware schedule (schedule_min_cost: gates moved between levels by the measured launch costs)
+    from go_tfhe_amd.circuits import schedule_min_cost
+    mc = schedule_min_cost(levels, C)
+    assert len(mc) == len(levels) and count_gates(mc) == count_gates(levels)
+    wt3 = torch.from_numpy(wires.view(np.int32)).cuda()
+    CircuitExecutor(ck128.ctx, mc, n_wires).run(wt3)
+    torch.cuda.synchronize()
+    assert torch.equal(wt3, wt)
     # one circuit re-done gate by gate on the oracle: identical ciphertexts on every wire it wrote
     c0 = 17
     ow = {w: wires[w, c0] for w in range(2 * bits)}

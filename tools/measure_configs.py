@@ -26,12 +26,12 @@ ck = pkg.CloudKey(p, bsk_torus=rnd((p.n, 2 * p.L, 2, p.N)), ksk=rnd((p.ksk_rows,
 n1 = p.n + 1
 # config 3: 8-bit ripple-carry adder x 256 circuits.  "reference" = the 40-gate circuit exactly as README.md:78-106
 # writes it (8 FullAdders from Constant(false): the contractual workload); "folded" = 37 gates (carry-in folded away).
-from go_tfhe_amd.circuits import balance_levels
+from go_tfhe_amd.circuits import balance_levels, schedule_min_cost
 for tag, fold in (("reference40", False), ("folded37", True)):
     levels, nw, sums, cout = ripple_carry_adder(8, fold_carry_in=fold)
     wires = torch.from_numpy(rnd((nw, 256, n1)).view(np.int32)).cuda()
     G = count_gates(levels) * 256
-    for sched, lv in (("asap", levels), ("balanced", balance_levels(levels, 1024 // 256))):
+    for sched, lv in (("asap", levels), ("balanced", balance_levels(levels, 1024 // 256)), ("mincost", schedule_min_cost(levels, 256))):
         ex = CircuitExecutor(ck.ctx, lv, nw)
         dt = timed(lambda: ex.run(wires), 5)
         graph = ex.capture(wires)
