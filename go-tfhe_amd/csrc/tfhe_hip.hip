@@ -412,9 +412,14 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
 }
 
 // Device work is issued in slabs of at most this many items, so the context's intermediate buffers have a fixed
-// size (16 co-resident launches' worth: 268 MB of TRLWE samples at N = 1024 with the MUX passes) however large
-// the batch -- after the first large call nothing is ever re-allocated under work in flight.
-int slab_items(const tfhe_ctx *c) { return 16 * (shape_is_512(c->shape) ? 8 : shape_is_1024(c->shape) ? 4 : 2) * c->num_cus; }
+// size (64 co-resident launches' worth = 65,536 bootstraps at N = 1024: 1.07 GB of TRLWE samples with the MUX passes)
+// however large the batch -- after the first large call nothing is ever re-allocated under work in flight.  Large
+// slabs because every MUX pass of a slab ends in one partly filled launch whose size the host does not know (the
+// list lengths live on the device): with 16,384-item slabs those tails were 7 % of a mixed gate stream.
+// Host-pointer batches are cut into pipe_items pieces (a quarter slab) so that transfers overlap the kernels.
+int launch_items(const tfhe_ctx *c) { return (shape_is_512(c->shape) ? 8 : shape_is_1024(c->shape) ? 4 : 2) * c->num_cus; }
+int slab_items(const tfhe_ctx *c) { return 64 * launch_items(c); }
+int pipe_items(const tfhe_ctx *c) { return 16 * launch_items(c); }
 
 // Scratch for slabs of up to `items` bootstraps (mux: with the three-pass MUX form).  hipMalloc is not allowed
 // while a stream is being captured: callers that capture run one call (or tfhe_ctx_reserve) beforehand.
@@ -546,13 +551,14 @@ int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t 
     return launch_keyswitch(c, acc[c->P.n & 1], d_out, B, nullptr, st);
 }
 
-// Host-pointer gate batch longer than one slab (16,384 bootstraps at N = 1024): the operands of slab s+1 go up and
-// the results of slab s-1 come down on their own streams while the kernels of slab s run, through double-buffered
-// staging of one slab each -- a Go caller can only hand over host memory, so for it this IS the throughput path.
+// Host-pointer gate batch longer than one piece (pipe_items: 16,384 bootstraps at N = 1024): the operands of piece s+1
+// go up and the results of piece s-1 come down on their own streams while the kernels of piece s run, through
+// double-buffered staging of one piece each -- a Go caller can only hand over host memory, so for it this IS the
+// throughput path.
 int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b,
                          const uint32_t *cc, uint32_t *out, int B)
 {
-    const int S = slab_items(c);
+    const int S = pipe_items(c);
     const size_t n1 = (size_t)c->P.n + 1, slab_rows = (size_t)S * n1 * 4;
     int rc;
     if ((rc = c->s_in0.reserve(2 * slab_rows)) || (rc = c->s_in1.reserve(2 * slab_rows)) || (rc = c->s_out.reserve(2 * slab_rows))) return rc;
@@ -1114,7 +1120,7 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
         }
     }
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    if (B > slab_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
+    if (B > pipe_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
     if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_in1.reserve(rows)) || (rc = c->s_out.reserve(rows))) return rc;
     if (cc && (rc = c->s_in2.reserve(rows))) return rc;

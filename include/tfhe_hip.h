@@ -89,8 +89,8 @@ int tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
 int tfhe_ctx_sync(tfhe_ctx *ctx);
 /* Sizes the context's intermediate device buffers for "_dev" batches of up to max_batch items (with_mux: for gate
  * batches that may contain MUX items) so that later calls allocate nothing -- required before capturing "_dev"
- * calls into a hipGraph.  Work is issued in slabs of 16 co-resident launches (16,384 bootstraps at N = 1024), so the
- * buffers stop growing there: 134 MB, 268 MB with MUX. */
+ * calls into a hipGraph.  Work is issued in slabs of 64 co-resident launches (65,536 bootstraps at N = 1024), so the
+ * buffers stop growing there: 0.54 GB, 1.07 GB with MUX. */
 int tfhe_ctx_reserve(tfhe_ctx *ctx, int max_batch, int with_mux);
 
 /* CloudKey.BootstrappingKey (cloudkey.go:16-21, []*trgsw.TRGSWLv1FFT, trgsw.go:60-68),

@@ -429,10 +429,10 @@ def test_random_batches_every_entry_point_agrees(oracle, keys_small, ck_small, p
 
 
 def test_host_pointer_batches_longer_than_a_slab(oracle, keys_small, ck_small, pkg):
-    # tfhe_gate_batch on more than one slab (16,384 bootstraps) moves slab s+1's operands up and slab s-1's results down
-    # while slab s computes (double-buffered staging, three streams).  Same words as the same items issued in pieces that
-    # each fit one slab (the un-pipelined path), with per-item ops incl. MUX, a ragged last slab, and twice in a row
-    # (buffer reuse across calls).
+    # tfhe_gate_batch on more than one pipeline piece (16,384 bootstraps) moves piece s+1's operands up and piece s-1's
+    # results down while piece s computes (double-buffered staging, three streams).  Same words as the same items issued in
+    # calls that each fit one piece (the un-pipelined path), with per-item ops incl. MUX, a ragged last piece, and twice in
+    # a row (buffer reuse across calls).
     k = keys_small
     B = 2 * 16384 + 37
     rs = np.random.RandomState(91)
