@@ -11,7 +11,8 @@
 //
 // Layouts (both operands are stored as the instruction's lanes read them: one 16-byte piece = 16 consecutive K of
 // one row / column):
-//   K order   K = (j N + i) 4 + k: piece kb = j N/4 + i/4 holds coefficients 4 (i/4) .. +3 of digit level j
+//   K order   K = (j N + i) base + k: piece kb = j N/4 + i/4 holds coefficients 4 (i/4) .. +3 of digit level j (base 4);
+//             with base 16 (Uint2) a piece is one coefficient's 16 candidates, kb = j N + i
 //   kskB      int8 [t N / 4][colsP][16]   colsP = 4 (n + 1) rounded up to 256; built once per key (k_ksk_mfma_pack)
 //   H         int8 [t N / 4][Mpad][16]    Mpad = ciphertexts rounded up to 256; built per launch (k_ks_onehot):
 //                                         a digit is the 32-bit word 1 << 8 d
@@ -29,57 +30,67 @@ typedef int ks_v4i __attribute__((ext_vector_type(4)));
 typedef int ks_v16i __attribute__((ext_vector_type(16)));
 
 
-// packed key [N][t][3][n1p] (k = 1..3; kernels.hpp) -> kskB
+// packed key [N][t][base - 1][n1p] (k = 1 .. base - 1; kernels.hpp) -> kskB.  BB = basebit: 2 (four coefficients per
+// 16-K piece) or 4 (one coefficient per piece).
+template <int BB>
 static __global__ void k_ksk_mfma_pack(const uint32_t *__restrict__ packed, uint4 *__restrict__ dst, int N, int t, int n1,
                                        int n1p, int colsP)
 {
+    constexpr int base = 1 << BB, DPP = 16 / base;          // digits per piece
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)t * (N / 4) * colsP;
+    const size_t total = (size_t)t * (N / DPP) * colsP;
     if (idx >= total) return;
     const int col = (int)(idx % colsP), kb = (int)(idx / colsP);
-    const int j = kb / (N / 4), i0 = 4 * (kb % (N / 4));
-    uint32_t w[4];
+    const int j = kb / (N / DPP), i0 = DPP * (kb % (N / DPP));
+    uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int ii = 0; ii < 4; ii++) {
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t u = 0;
-            if (k > 0 && col < 4 * n1) {
-                const uint32_t word = packed[((size_t)((i0 + ii) * t + j) * 3 + (k - 1)) * n1p + (col >> 2)];
-                u = (word >> (8 * (col & 3))) & 0xFFu;
-            }
-            v |= (u ^ 0x80u) << (8 * k);
+    for (int b = 0; b < 16; b++) {                          // byte b of the piece: coefficient i0 + b / base, candidate k = b % base
+        const int ii = b / base, k = b % base;
+        uint32_t u = 0;
+        if (k > 0 && col < 4 * n1) {
+            const uint32_t word = packed[((size_t)((i0 + ii) * t + j) * (base - 1) + (k - 1)) * n1p + (col >> 2)];
+            u = (word >> (8 * (col & 3))) & 0xFFu;
         }
-        w[ii] = v;
+        w[b >> 2] |= (u ^ 0x80u) << (8 * (b & 3));
     }
     dst[idx] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Sample extract at index 0 (trlwe_ops.go:13-19) + digit decomposition (keyswitch.go:14-16,25-29) -> H.
-// Workgroup = 16 ciphertexts x 16 coefficient quads; stores of one digit level are 256 contiguous bytes per quad.
+// Workgroup = 16 ciphertexts x 16 coefficient quads; stores of one digit level are 256 contiguous bytes per piece.
+template <int BB>
 static __global__ __launch_bounds__(256) void k_ks_onehot(const uint32_t *__restrict__ trlwe, uint4 *__restrict__ H, int N, int t,
                                                           int M, int Mpad, const int *__restrict__ count, int m_base)
 {
+    constexpr int base = 1 << BB, DPP = 16 / base;
     const int tid = threadIdx.x, m = 16 * blockIdx.x + (tid & 15), iq = 16 * blockIdx.y + (tid >> 4);
     int live_items = M;
     if (count) { const int c = *count - m_base; live_items = c < M ? (c < 0 ? 0 : c) : M; }
     // rows past the live items stay as they are: the rows of a matrix product are independent and k_keyswitch_mfma
     // never stores theirs
     if (m >= live_items) return;
-    const uint32_t prec = 1u << (32 - (1 + 2 * t));
+    const uint32_t prec = 1u << (32 - (1 + BB * t));
     uint32_t w[4];
     const uint32_t *ta = trlwe + (size_t)m * 2 * N;
 #pragma unroll
     for (int ii = 0; ii < 4; ii++) {
         const int i = 4 * iq + ii;
         const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
-        w[ii] = (ai + prec) >> (32 - 2 * t);                  // t digits, most significant first
+        w[ii] = (ai + prec) >> (32 - BB * t);                 // t digits, most significant first
     }
     for (int j = 0; j < t; j++) {
-        const int sh = 2 * (t - 1 - j);
-        H[((size_t)j * (N / 4) + iq) * Mpad + m] = make_uint4(1u << (8 * ((w[0] >> sh) & 3)), 1u << (8 * ((w[1] >> sh) & 3)),
-                                                              1u << (8 * ((w[2] >> sh) & 3)), 1u << (8 * ((w[3] >> sh) & 3)));
+        const int sh = BB * (t - 1 - j);
+        if (DPP == 4) {                                       // a digit is the word 1 << 8 d
+            H[((size_t)j * (N / 4) + iq) * Mpad + m] = make_uint4(1u << (8 * ((w[0] >> sh) & 3)), 1u << (8 * ((w[1] >> sh) & 3)),
+                                                                  1u << (8 * ((w[2] >> sh) & 3)), 1u << (8 * ((w[3] >> sh) & 3)));
+        } else {                                              // a digit is a whole piece: byte d of 16 set
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++) {
+                const uint32_t d = (w[ii] >> sh) & (base - 1), bit = 1u << (8 * (d & 3));
+                H[((size_t)j * N + 4 * iq + ii) * Mpad + m] = make_uint4((d >> 2) == 0 ? bit : 0u, (d >> 2) == 1 ? bit : 0u,
+                                                                         (d >> 2) == 2 ? bit : 0u, (d >> 2) == 3 ? bit : 0u);
+            }
+        }
     }
 }
 

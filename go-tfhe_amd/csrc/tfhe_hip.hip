@@ -254,17 +254,26 @@ int make_quad_key(tfhe_ctx *c, hipStream_t st)
 // Byte-column copy of the packed key-switching key for k_keyswitch_mfma (base-4 sets; keyswitch_mfma.hpp).
 constexpr int kKsMfmaMinDefault = 1;        // it wins from one ciphertext on (0.09 vs 0.27 ms; 0.135 vs 0.51 ms at 1,024)
 constexpr int kKsMfmaChunk = 1024;           // ciphertexts per one-hot matrix (38 MB at the 128-bit set)
-bool ks_mfma_shape(const tfhe_params &P) { return P.basebit == 2 && P.N % 64 == 0 && 1 + 2 * P.t <= 32 && (P.t * P.N / 8) % (2 * kKsStage) == 0; }
+int ks_mfma_pieces(const tfhe_params &P) { return P.t * P.N / (16 >> P.basebit); }      // 16-K pieces: K = N t base
+bool ks_mfma_shape(const tfhe_params &P)
+{
+    return (P.basebit == 2 || P.basebit == 4) && P.N % 64 == 0 && 1 + P.basebit * P.t <= 32 && (ks_mfma_pieces(P) / 2) % (2 * kKsStage) == 0;
+}
 int ks_mfma_cols(const tfhe_params &P) { return (4 * (P.n + 1) + kKsGroup - 1) / kKsGroup * kKsGroup; }
 int make_mfma_ksk(tfhe_ctx *c, hipStream_t st)
 {
     if (!ks_mfma_shape(c->P) || c->ks_mfma_min <= 0) return TFHE_OK;
     const int colsP = ks_mfma_cols(c->P);
-    const size_t pieces = (size_t)c->P.t * (c->P.N / 4) * colsP;
+    const size_t pieces = (size_t)ks_mfma_pieces(c->P) * colsP;
     int rc;
     if ((rc = c->kskB.reserve(pieces * sizeof(uint4)))) return rc;
-    hipLaunchKernelGGL(k_ksk_mfma_pack, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, c->ksk.as<uint32_t>(),
-                       c->kskB.as<uint4>(), c->P.N, c->P.t, c->P.n + 1, c->n1p, colsP);
+    const dim3 grid((unsigned)((pieces + 255) / 256));
+    if (c->P.basebit == 2)
+        hipLaunchKernelGGL(k_ksk_mfma_pack<2>, grid, dim3(256), 0, st, c->ksk.as<uint32_t>(), c->kskB.as<uint4>(), c->P.N, c->P.t,
+                           c->P.n + 1, c->n1p, colsP);
+    else
+        hipLaunchKernelGGL(k_ksk_mfma_pack<4>, grid, dim3(256), 0, st, c->ksk.as<uint32_t>(), c->kskB.as<uint4>(), c->P.N, c->P.t,
+                           c->P.n + 1, c->n1p, colsP);
     HIP_TRY(hipGetLastError());
     return TFHE_OK;
 }
@@ -324,19 +333,19 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     const bool mfma = c->kskB.p && c->ks_mfma_min > 0 && B >= c->ks_mfma_min;
     if (mfma) {                 // the one-hot matrix of one chunk (a no-op after reserve_scratch / the first call)
         const int Bc = B < kKsMfmaChunk ? B : kKsMfmaChunk, MpadMax = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
-        int rc = c->s_onehot.reserve((size_t)c->P.t * (c->P.N / 4) * MpadMax * sizeof(uint4));
+        int rc = c->s_onehot.reserve((size_t)ks_mfma_pieces(c->P) * MpadMax * sizeof(uint4));
         if (rc) return rc;
     }
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
-    // base-4 sets, batches: the exact int8 matrix-core form (keyswitch_mfma.hpp), in chunks of kKsMfmaChunk ciphertexts
+    // base-4 and base-16 sets: the exact int8 matrix-core form (keyswitch_mfma.hpp), in chunks of kKsMfmaChunk ciphertexts
     if (mfma) {
         const int N = c->P.N, t = c->P.t, n1 = c->P.n + 1, colsP = ks_mfma_cols(c->P);
         const size_t tot = (size_t)B * n1;
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, N, B, d_count);
         const uint32_t bias_word = (uint32_t)((unsigned long long)(128ull * N * t) * 0x01010101ull);
-        const int pairs_total = t * N / 8 / (2 * kKsStage), n_groups = colsP / kKsGroup;
+        const int pairs_total = ks_mfma_pieces(c->P) / 2 / (2 * kKsStage), n_groups = colsP / kKsGroup;
         for (int m_base = 0; m_base < B; m_base += kKsMfmaChunk) {
             const int M = B - m_base < kKsMfmaChunk ? B - m_base : kKsMfmaChunk;
             const int Mpad = (M + kKsGroup - 1) / kKsGroup * kKsGroup, m_groups = Mpad / kKsGroup;
@@ -349,8 +358,12 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
             if (parts > pairs_total) parts = pairs_total;
             const int per_part = (pairs_total + parts - 1) / parts;
             parts = (pairs_total + per_part - 1) / per_part;
-            hipLaunchKernelGGL(k_ks_onehot, dim3(Mpad / 16, N / 64), dim3(256), 0, st, d_trlwe + (size_t)m_base * 2 * N,
-                               c->s_onehot.as<uint4>(), N, t, M, Mpad, d_count, m_base);
+            if (c->P.basebit == 2)
+                hipLaunchKernelGGL(k_ks_onehot<2>, dim3(Mpad / 16, N / 64), dim3(256), 0, st, d_trlwe + (size_t)m_base * 2 * N,
+                                   c->s_onehot.as<uint4>(), N, t, M, Mpad, d_count, m_base);
+            else
+                hipLaunchKernelGGL(k_ks_onehot<4>, dim3(Mpad / 16, N / 64), dim3(256), 0, st, d_trlwe + (size_t)m_base * 2 * N,
+                                   c->s_onehot.as<uint4>(), N, t, M, Mpad, d_count, m_base);
             const int work = m_groups * n_groups * parts, grid = (work + 7) / 8 * 8;      // a multiple of the 8 XCDs (see the kernel)
             hipLaunchKernelGGL(k_keyswitch_mfma, dim3((unsigned)grid), dim3(512), 0, st,
                                c->s_onehot.as<uint4>(), c->kskB.as<uint4>(), d_out + (size_t)m_base * n1, Mpad, colsP, n1, M, d_count,
@@ -431,7 +444,7 @@ int reserve_scratch(tfhe_ctx *c, int items, bool mux)
     if ((rc = c->s_trlwe.reserve(mux ? 2 * trl : trl))) return rc;
     if (c->kskB.p) {            // one-hot digit matrix of the matrix-core key switch (one chunk; launch_keyswitch)
         const int Bc = S < kKsMfmaChunk ? S : kKsMfmaChunk, Mpad = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
-        if ((rc = c->s_onehot.reserve((size_t)c->P.t * (c->P.N / 4) * Mpad * sizeof(uint4)))) return rc;
+        if ((rc = c->s_onehot.reserve((size_t)ks_mfma_pieces(c->P) * Mpad * sizeof(uint4)))) return rc;
     }
     if (mux) {
         const int nb = (S + kPlanBlock - 1) / kPlanBlock;

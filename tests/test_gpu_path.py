@@ -105,20 +105,26 @@ def test_extract_keyswitch_tiled_kernel_bit_exact(oracle, request, which, B):
         assert np.array_equal(got[b], want), b
 
 
-@pytest.mark.parametrize("which", ["small", "80", "128"])
+@pytest.mark.parametrize("which", ["small", "80", "128", "uint2"])
 def test_matrix_core_keyswitch_equals_vector_kernels(pkg, oracle, request, which, monkeypatch):
     # csrc/keyswitch_mfma.hpp (the default for the base-4 sets: exact int8 matrix product over byte columns) against the
     # vector-ALU kernels of csrc/kernels.hpp (TFHE_KS_MFMA_MIN=0: per-ciphertext gather below 32, the tiled kernel above)
     # on the same key and inputs, bit for bit, across the tile edges (256-row groups, 1,024-row chunks) -- and both
     # against the oracle on a sample.
-    k = request.getfixturevalue({"small": "keys_small", "80": "keys80", "128": "keys128"}[which])
+    # "uint2": base 16 (one coefficient's 16 candidate rows per 16-K piece), N = 512, a random key of reduced dimension.
+    if which == "uint2":
+        from types import SimpleNamespace
+        p2 = oracle.params("uint2").small(40)
+        k = SimpleNamespace(p=p2, ksk=rand_u32(np.random.RandomState(29), (p2.N * p2.t * (1 << p2.basebit), p2.n + 1)))
+    else:
+        k = request.getfixturevalue({"small": "keys_small", "80": "keys80", "128": "keys128"}[which])
     monkeypatch.setenv("TFHE_KS_MFMA_MIN", "0")
     ckv = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
     monkeypatch.delenv("TFHE_KS_MFMA_MIN")
     ckm = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
     rs = np.random.RandomState(23)
-    for B in ((1, 5, 33, 256, 257, 1025, 2100) if which == "small" else (1, 33, 300)):
-        trl = rand_u32(rs, (B, 2, 1024))
+    for B in ((1, 5, 33, 256, 257, 1025, 2100) if which in ("small", "uint2") else (1, 33, 300)):
+        trl = rand_u32(rs, (B, 2, k.p.N))
         trl[0] = 0
         trl[B // 2] = 0xFFFFFFFF
         a, b = ckv.ctx.extract_keyswitch_batch(trl), ckm.ctx.extract_keyswitch_batch(trl)
