@@ -132,7 +132,209 @@ def cpu_baseline(key, a, b, budget_s=12.0):
     return {"value": S / dt, "unit": "gates/s", "cores": used, "kind": "port",
             "sample": f"{S} of the same {a.shape[0]} NAND gates, one bootstrap per thread; "
                       f"gcc -O2 scalar radix-2 FFT port of the Go reference",
-            "single_thread_ms_per_gate": one * 1e3}
+            "single_thread_ms_per_gate": one * 1e3, **cpu_description()}
+
+
+def cpu_description():
+    """CPU model / logical CPUs / the compiler flags of the oracle build: the context SURVEY 8d asks for beside cpu_baseline."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    flags = None
+    try:
+        for ln in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if ln.startswith("CFLAGS"):
+                flags = ln.split("=", 1)[1].strip()
+    except Exception:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "usable_cores": effective_cores(), "compiler": "gcc", "flags": flags}
+
+
+def measured_ceilings():
+    """tools/ubench_ceilings.bin on THIS box (built by __graft_entry__.build()): fp64 issue rate per SIMD at 1 / 2 / 4
+    resident waves and the device-copy bandwidth.  None when the binary is missing or fails (never fatal)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "ubench_ceilings.bin")
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+# VALU instructions a wave of k_blind_rotate<3,6,4> issues per CMUX step (SQ_INSTS_VALU / waves / steps of the committed
+# rocprofv3 PMC pass, profiles/r02_i_pmc_summary.txt: 2.197e9 / 2048 / 700; unchanged this round) and its occupancy:
+# what `roofline.attainable` is computed from
+BR_VALU_PER_WAVE_STEP = 1532
+BR_WAVES_PER_SIMD = 2
+
+
+class KernelTimer:
+    """Blind-rotate launches and their summed duration (HIP events recorded by the library on the launch stream)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def __enter__(self):
+        self.ctx.timing_enable(True)
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.timing_enable(False)
+        self.br_n, self.br_ms = self.ctx.timing_read(0)
+        self.ks_n, self.ks_ms = self.ctx.timing_read(1)
+
+
+def extra_configs(pkg, key, ck, dev):
+    """BASELINE configs 3, 4 and 5 (one GPU's share) AFTER the headline's timed region: each with its own timed loop, the
+    blind-rotate share of it, that kernel family's fp64 fraction, and `verified` from checks done outside the timed loops
+    (decrypt-level for everything, bit-equality with the oracle on samples where the parameter set is exact)."""
+    import torch
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor, schedule_min_cost, count_gates
+    o, p = key.o, key.p
+    n1 = p.n + 1
+    out = {}
+
+    def timed(fn, reps, ctx):
+        fn(); torch.cuda.synchronize()
+        with KernelTimer(ctx) as kt:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+        return dt, kt
+
+    def kernel_part(kt, reps, bootstraps, pp):
+        fl = fp64_flops_per_bootstrap(pp) * bootstraps * reps
+        tf = fl / (kt.br_ms * 1e-3) / 1e12 if kt.br_ms else None
+        return {"blind_rotate_ms_per_run": kt.br_ms / reps, "blind_rotate_launches_per_run": kt.br_n // reps,
+                "keyswitch_ms_per_run": kt.ks_ms / reps, "fp64_tflops": tf, "fp64_frac": tf / FP64_VECTOR_PEAK_TFLOPS if tf else None}
+
+    # ---- config 3: 8-bit ripple-carry adder exactly as the reference writes it (40 gates, README.md:78-106) x 256 circuits
+    try:
+        C, bits = 256, 8
+        levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+        sched = schedule_min_cost(levels, C)
+        rs = np.random.RandomState(KEY_SEED + 3)
+        av, bv = rs.randint(0, 256, C), rs.randint(0, 256, C)
+        wires = np.zeros((n_wires, C, n1), np.uint32)
+        for i in range(bits):
+            wires[i] = key.enc((av >> i) & 1, 3000 + i)
+            wires[bits + i] = key.enc((bv >> i) & 1, 3100 + i)
+        cw = adder_constant_wire(bits)
+        wires[cw] = pkg.gates.Constant(False, p)
+        wt = torch.from_numpy(wires.view(np.int32)).to(dev)
+        ex = CircuitExecutor(ck.ctx, sched, n_wires)
+        G = count_gates(sched) * C
+        dt, kt = timed(lambda: ex.run(wt), 5, ck.ctx)
+        res = wt.cpu().numpy().view(np.uint32)
+        got = sum(key.dec(np.ascontiguousarray(res[w])).astype(np.int64) << i for i, w in enumerate(sums))
+        got += key.dec(np.ascontiguousarray(res[cout])).astype(np.int64) << bits
+        sums_ok = bool(np.array_equal(got, av + bv))
+        c0 = 101                                         # one circuit again on the oracle, every wire compared
+        ow = {w: wires[w, c0] for w in list(range(2 * bits)) + [cw]}
+        for lvl in levels:
+            for (op, x, y, z, w_out) in lvl:
+                ow[w_out] = o.gate(p, key.bsk, key.ksk, op, np.ascontiguousarray(ow[x]), np.ascontiguousarray(ow[y]))
+        wires_ok = all(bool(np.array_equal(res[w, c0], v)) for w, v in ow.items())
+        out["config3_adder8_x256"] = {
+            "workload": "BASELINE configs[2]: 8-bit ripple-carry adder as the reference writes it (8 FullAdders from Constant(false), 40 gates, "
+                        "17 levels) x 256 circuits, 128-bit params, one GPU; cost-aware schedule (circuits.schedule_min_cost)",
+            "gates": G, "level_widths": [len(l) for l in sched], "seconds": dt, "rate": G / dt, "unit": "gates/s",
+            "additions_per_s": C / dt, "dominant_kernel": "k_blind_rotate_oct / k_blind_rotate (by level width)",
+            **kernel_part(kt, 5, G, pkg.params.Security128Bit),
+            "verified": sums_ok and wires_ok,
+            "checks": {"all_256_sums_and_carries_decrypt_to_a_plus_b": sums_ok,
+                       "every_wire_of_one_circuit_bit_identical_to_oracle": wires_ok}}
+    except Exception as e:                                   # a failing extra config must not take the headline line down
+        out["config3_adder8_x256"] = {"error": f"{type(e).__name__}: {e}", "verified": False}
+
+    # ---- config 5 (one GPU's share of the 1M-gate stream): 131,072 mixed AND / OR / XOR / MUX gates
+    try:
+        total = 131072
+        rs = np.random.RandomState(KEY_SEED + 5)
+        pool_bits = rs.randint(0, 2, 256)
+        pool_h = key.enc(pool_bits, 5000)
+        pool = torch.from_numpy(pool_h.view(np.int32)).to(dev)
+        ia_h, ib_h, ic_h = (rs.randint(0, 256, total) for _ in range(3))
+        names = np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, total)]           # AND, OR, XOR, MUX
+        ops = torch.from_numpy(names).to(dev)
+        a, b, c = (pool[torch.from_numpy(ix).to(dev)].contiguous() for ix in (ia_h, ib_h, ic_h))
+        res_t = torch.zeros_like(a)
+        ck.ctx.reserve(total, with_mux=True)
+        dt, kt = timed(lambda: ck.ctx.gate_batch_dev(ops, a, b, c, res_t), 1, ck.ctx)
+        ck.ctx.sync()
+        r = res_t.cpu().numpy().view(np.uint32)
+        A, Bb, Cc = (pool_bits[ix].astype(bool) for ix in (ia_h, ib_h, ic_h))
+        want = np.where(names == 1, A & Bb, np.where(names == 2, A | Bb, np.where(names == 3, A ^ Bb, np.where(A, Bb, Cc))))
+        sel = np.arange(0, total, 32)
+        dec_ok = bool(np.array_equal(key.dec(np.ascontiguousarray(r[sel])), want[sel]))
+        first = {code: int(np.argmax(names == code)) for code in (1, 2, 3, 10)}      # one gate of each kind on the oracle
+        opname = {1: "AND", 2: "OR", 3: "XOR", 10: "MUX"}
+        bit_ok = True
+        for code, g in first.items():
+            w = o.gate(p, key.bsk, key.ksk, opname[code], np.ascontiguousarray(pool_h[ia_h[g]]), np.ascontiguousarray(pool_h[ib_h[g]]),
+                       np.ascontiguousarray(pool_h[ic_h[g]]) if code == 10 else None)
+            bit_ok &= bool(np.array_equal(r[g], w))
+        nb = int((names == 10).sum()) * 3 + int((names != 10).sum())
+        out["config5_mixed_stream_131072"] = {
+            "workload": "BASELINE configs[4], one GPU's share (1/8 of the 1M-gate stream): 131,072 mixed AND/OR/XOR/MUX gates on a pool of "
+                        "encrypted bits, 128-bit params; MUX = 3 bootstraps (gates.go:107-114), split on the device",
+            "gates": total, "bootstraps": nb, "seconds": dt, "rate": total / dt, "unit": "gates/s", "bootstraps_per_s": nb / dt,
+            "dominant_kernel": "k_blind_rotate<3,6,4>", **kernel_part(kt, 1, nb, pkg.params.Security128Bit),
+            "verified": dec_ok and bit_ok,
+            "checks": {"4096_sampled_outputs_decrypt_correctly": dec_ok, "one_gate_of_each_kind_bit_identical_to_oracle": bit_ok}}
+        del a, b, c, res_t, pool
+    except Exception as e:
+        out["config5_mixed_stream_131072"] = {"error": f"{type(e).__name__}: {e}", "verified": False}
+
+    # ---- config 4: programmable bootstrap, Uint5 (N = 2048, n = 1071), LUT evaluation, batch 512
+    ck5 = None
+    try:
+        B, m = 512, 32
+        p5o = o.params("uint5")
+        p5 = pkg.params.SecurityUint5
+        rng = o.rng(KEY_SEED + 4)
+        s0, s1 = o.keygen_secret(p5o, rng)
+        ck5 = pkg.CloudKey.NewCloudKey(p5, s0, s1, p5o.alpha_lv0, p5o.alpha_lv1, seed=KEY_SEED + 4)     # cloudkey.NewCloudKey on the GPU
+        rs = np.random.RandomState(KEY_SEED + 4)
+        msgs = rs.randint(0, m, B)
+        table = [(x % 16) for x in range(m)]                          # one of the adder LUTs of examples/add_two_numbers/main.go:59-72
+        lut_h = o.lut_generate(p5o, table)
+        cts_h = np.stack([o.encrypt_message(p5o, rng, int(x), m, s0) for x in msgs])
+        cts = torch.from_numpy(cts_h.view(np.int32)).to(dev)
+        lut = torch.from_numpy(lut_h.view(np.int32)).to(dev)
+        res_t = torch.zeros_like(cts)
+        dt, kt = timed(lambda: ck5.ctx.bootstrap_batch_dev(cts, lut, res_t), 10, ck5.ctx)
+        ck5.ctx.sync()
+        r = res_t.cpu().numpy().view(np.uint32)
+        dec = np.array([o.decrypt_message(p5o, m, s0, np.ascontiguousarray(r[i])) for i in range(B)])
+        dec_ok = bool(np.array_equal(dec, np.array(table)[msgs]))
+        ph = np.array([o.phase(p5o, s0, np.ascontiguousarray(r[i])) for i in range(B)]).astype(np.int64)
+        ideal = (np.array(table)[msgs].astype(np.int64) * (2**31 // m)) % 2**32
+        dist = np.minimum((ph - ideal) % 2**32, (ideal - ph) % 2**32)
+        phase_ok = bool(dist.max() <= 2**32 // (4 * m))
+        out["config4_pbs_uint5_x512"] = {
+            "workload": "BASELINE configs[3]: programmable bootstrap (evaluator.BootstrapLUTAssign, programmable_bootstrap.go:93-115), Uint5 params "
+                        "(n=1071, N=2048, L=1, Bgbit=22), LUT x mod 16 over Z_32, batch 512; cloud key generated on the GPU",
+            "pbs": B, "seconds": dt, "rate": B / dt, "unit": "PBS/s", "dominant_kernel": "k_blind_rotate_2048<22>",
+            **kernel_part(kt, 10, B, p5),
+            "verified": dec_ok and phase_ok,
+            "checks": {"all_512_decrypt_to_lut_of_message": dec_ok, "output_phase_within_2^32/(4*32)_of_ideal": phase_ok,
+                       "max_phase_distance": int(dist.max()),
+                       "ciphertext_level": "tolerance regime (values reach 2^58 > 2^53: SURVEY 8c(4)); per-step ciphertext checks are in tests/test_gpu_uint5.py"}}
+    except Exception as e:
+        out["config4_pbs_uint5_x512"] = {"error": f"{type(e).__name__}: {e}", "verified": False}
+    finally:
+        if ck5 is not None:
+            ck5.close()
+    return out
 
 
 def emit(line):
@@ -153,6 +355,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3/4/5 and the ceiling micro-benchmarks after the headline")
     ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
     ap.add_argument("--workload", choices=["mixed", "adder"], default="mixed", help="--mode sharded only")
     ap.add_argument("--gates", type=int, default=0, help="--mode sharded --workload mixed: total gates (default 131072 per rank)")
@@ -284,7 +487,7 @@ def main():
             "metric": "gate bootstraps/sec (NAND, 128-bit params)",
             "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "verified": verified,
+            "dtype": "f64", "data": "synthetic (real encryptions of random bits under a seeded cloud key; no external dataset)", "verified": verified,
             "config": {"workload": "BASELINE configs[1]: batch of 1024 independent NAND bootstraps per GPU, "
                                    "128-bit params (n=700, N=1024, L=3, Bgbit=6, t=9), keys+inputs resident in HBM",
                        "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)",
@@ -312,6 +515,26 @@ def main():
         }
         if key_broadcast_ms is not None:
             line["key_broadcast_ms"] = key_broadcast_ms
+        if world == 1 and not args.no_configs:
+            # measured ceilings of THIS box beside the nominal peaks (tools/ubench_ceilings.hip)
+            ceil = measured_ceilings()
+            line["measured_ceilings"] = ceil
+            try:
+                ns = ceil["fp64_issue"][f"fma_wps{BR_WAVES_PER_SIMD}"]["ns_per_instr_per_simd"]
+                # the time the kernel's own VALU instruction stream needs at the measured issue rate of its occupancy
+                t_min_ms = BR_WAVES_PER_SIMD * p.n * BR_VALU_PER_WAVE_STEP * ns * 1e-6
+                att = fp64_flops_per_bootstrap(p) * BATCH / (t_min_ms * 1e-3) / 1e12
+                line["roofline"]["attainable"] = att
+                line["roofline"]["frac_of_attainable"] = tflops / att
+                line["roofline"]["attainable_note"] = (
+                    f"fp64 Tflop/s if the kernel's {BR_VALU_PER_WAVE_STEP} VALU instructions per wave and CMUX step issued at the rate "
+                    f"tools/ubench_ceilings measured on this box for {BR_WAVES_PER_SIMD} resident waves per SIMD ({ns:.3f} ns per instruction per SIMD; "
+                    "the nominal peak assumes one every 4 cycles and 2 flop per lane, an FFT's mix is 1.42)")
+                line["roofline"]["hbm_streaming"]["measured_copy_GBps"] = ceil["hbm_copy"]["kernel_copy_GBps"]
+                line["roofline"]["hbm_streaming"]["x_measured_copy"] = stream_gbs / ceil["hbm_copy"]["kernel_copy_GBps"]
+            except Exception:
+                pass
+            line["configs"] = extra_configs(pkg, key, ck, dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(key, a_h, b_h)
     ck.close()

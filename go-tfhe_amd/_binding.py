@@ -68,9 +68,11 @@ def load_library():
         "tfhe_ctx_reserve": [vp, C.c_int, C.c_int],
         "tfhe_key_size": [vp, C.c_int, C.POINTER(C.c_size_t)],
         "tfhe_key_export_dev": [vp, C.c_int, vp, vp],
-        "tfhe_key_import_dev": [vp, C.c_int, vp, vp],
+        "tfhe_key_import_dev": [vp, C.c_int, vp, C.c_size_t, vp],
         "tfhe_key_export": [vp, C.c_int, vp],
-        "tfhe_key_import": [vp, C.c_int, vp],
+        "tfhe_key_import": [vp, C.c_int, vp, C.c_size_t],
+        "tfhe_ctx_set_option": [vp, C.c_int, C.c_int],
+        "tfhe_ctx_get_option": [vp, C.c_int, C.POINTER(C.c_int)],
         "tfhe_keygen_cloud_seeded": [vp, u32p, u32p, C.c_double, C.c_double, C.POINTER(C.c_uint64)],
         "tfhe_bootstrap_batch": [vp, u32p, u32p, C.c_int, u32p, C.c_int],
         "tfhe_bootstrap_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, vp],
@@ -92,6 +94,8 @@ def load_library():
         "tfhe_timing_read": [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float)],
     }
     for name, args in sig.items():
+        if not hasattr(lib, name) and os.environ.get("TFHE_HIP_LIB"):
+            continue        # an older experiment build under tools/ab_bench.py; the shipped library must export everything
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int
@@ -382,10 +386,10 @@ class Context:
         return blob
 
     def key_import(self, which, blob):
+        """Install a blob from key_export; the library checks its header (parameter set, key kind, layout version,
+        length) and raises TfheError when it does not belong to this context."""
         blob = np.ascontiguousarray(blob, np.uint8)
-        if blob.size != self.key_size(which):
-            raise ValueError(f"key blob: expected {self.key_size(which)} bytes, got {blob.size}")
-        self._check(self._lib.tfhe_key_import(self._h, int(which), blob.ctypes.data_as(C.c_void_p)))
+        self._check(self._lib.tfhe_key_import(self._h, int(which), blob.ctypes.data_as(C.c_void_p), blob.size))
 
     def key_export_dev(self, which, stream=None):
         """The loaded key `which` (0 = bootstrapping, 1 = key-switching) as an opaque uint8 GPU tensor."""
@@ -395,10 +399,22 @@ class Context:
         return blob
 
     def key_import_dev(self, which, blob, stream=None):
-        if not blob.is_cuda or not blob.is_contiguous() or blob.numel() * blob.element_size() != self.key_size(which) \
-                or blob.device.index != self.device:
-            raise ValueError("key blob: need a contiguous tensor of key_size(which) bytes on the context's GPU")
-        self._check(self._lib.tfhe_key_import_dev(self._h, int(which), C.c_void_p(blob.data_ptr()), self._stream(stream)))
+        if not blob.is_cuda or not blob.is_contiguous() or blob.device.index != self.device:
+            raise ValueError("key blob: need a contiguous tensor on the context's GPU")
+        self._check(self._lib.tfhe_key_import_dev(self._h, int(which), C.c_void_p(blob.data_ptr()),
+                                                  blob.numel() * blob.element_size(), self._stream(stream)))
+
+    OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4}
+
+    def set_option(self, name, value):
+        """tfhe_ctx_set_option: kernel-dispatch limits for measurements and tests ("quad_max", "oct_max", "ks_mfma_min";
+        a negative value restores the default) and the "frozen" flag (include/tfhe_hip.h)."""
+        self._check(self._lib.tfhe_ctx_set_option(self._h, self.OPTIONS[name], int(value)))
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._check(self._lib.tfhe_ctx_get_option(self._h, self.OPTIONS[name], C.byref(v)))
+        return v.value
 
     def reserve(self, max_batch, with_mux=False):
         """Pre-size the intermediate buffers (needed before capturing _dev calls into a graph)."""

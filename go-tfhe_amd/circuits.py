@@ -196,9 +196,13 @@ class CircuitExecutor:
     def capture(self, wires):
         """Record run(wires) into a HIP graph (torch.cuda.CUDAGraph) and return it; replay() re-runs the whole
         circuit on whatever the wire tensor holds at that time.  tfhe_gate_batch_dev only enqueues (no read-back,
-        no synchronisation), so the level loop captures as is; one un-captured run first sizes the context's
-        intermediate buffers and fills the op-code cache (neither may allocate during capture)."""
+        no synchronisation), so the level loop captures as is.  Before capturing, the context's intermediate buffers
+        are sized for ANY later batch (tfhe_ctx_reserve up to a full slab, with the MUX buffers): the graph records
+        their addresses, the library freezes them at the first captured call, and a context that could still need
+        to grow one would have to refuse that later call (include/tfhe_hip.h, tfhe_ctx_reserve).  One un-captured
+        run fills the op-code cache and warms torch's allocator (neither may allocate during capture)."""
         torch = self.torch
+        self.ctx.reserve(1 << 30, with_mux=True)
         self.run(wires)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()

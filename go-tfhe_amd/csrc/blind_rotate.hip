@@ -19,11 +19,7 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
     // N=512: one wave and 16 KB LDS per bootstrap, 2 waves per SIMD -> 8 per CU.
     // N = 1024, launches of up to quad_max items: four waves per bootstrap (kernels_quad.hpp)
     const int quad_max = a0.bskq ? quad_limit : 0;
-#ifdef OCC3
-    const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 6 : 2) * num_cus;      // six 2-wave workgroups per CU
-#else
     const int cap = (shape_is_512(shape) ? 8 : shape_is_1024(shape) ? 4 : 2) * num_cus;
-#endif
     for (int base = 0; base < B; base += cap) {
         const int cnt = B - base < cap ? B - base : cap;
         BlindRotateArgs a = a0;
@@ -51,9 +47,6 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
             }
             continue;
         }
-#ifdef OCC3
-        if (shape == kShapeN1024_L3_B6 && cnt > num_cus) { hipLaunchKernelGGL((k_blind_rotate<3, 6>), g, dim3(128), 0, st, a); continue; }
-#endif
         // Several items per workgroup (they share only the barriers), measured A/B on one box:
         //   769..1024 items: FOUR per 8-wave workgroup = every resident wave of a CU in one workgroup, in step on
         //                    the key stream: 6.84 (one item) -> 6.66 (two) -> 6.38 ms (four) at 1024;
@@ -84,9 +77,11 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_blind_rotate<1, 23>), g, dim3(128), 0, st, a); break;
         case kShapeN512_L1_B18: hipLaunchKernelGGL((k_blind_rotate_512<18>), g, dim3(64), 0, st, a); break;
         default:
-            // more than one 4-wave workgroup per CU: two bootstraps per 8-wave workgroup (7.01 -> 6.85 ms at 512)
-            if (cnt > num_cus) { hipLaunchKernelGGL((k_blind_rotate_2048<22, 2>), dim3((cnt + 1) / 2), dim3(512), 0, st, a); break; }
-            hipLaunchKernelGGL((k_blind_rotate_2048<22>), g, dim3(256), 0, st, a); break;
+            // one bootstrap per four-wave workgroup whatever the launch size (two bootstraps per eight-wave workgroup
+            // were 2 % faster while a step had five barriers; with four, free-running workgroups win by 7 %)
+            if (cnt <= num_cus) hipLaunchKernelGGL((k_blind_rotate_2048<22, true>), g, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_blind_rotate_2048<22, false>), g, dim3(256), 0, st, a);
+            break;
         }
     }
 }

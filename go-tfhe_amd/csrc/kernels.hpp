@@ -245,8 +245,7 @@ __device__ __forceinline__ uint32_t diff_coeff(const DiffSource &S, int j)
 template <int L, int BGBIT>
 __device__ __forceinline__ void external_product_core(const DiffSource &S, uint32_t (&e)[16],
                                                       const cd *__restrict__ key_ip, /* &bsk[i][p] */
-                                                      const cd *__restrict__ key_next, /* level 0 of the next step or nullptr */
-                                                      KeyRegs &K, /* in: level 0 of this step; out: key_next */
+                                                      KeyRegs &K, /* scratch: the level's key slices */
                                                       cd *sc_mine, const cd *sc_other,
                                                       const cd *__restrict__ table, const LaneTwiddles &tw,
                                                       uint32_t offset, int p, int lane, PhaseClock &clk)
@@ -269,8 +268,6 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         }
     }
     clk.mark(0);
-#ifdef FFT_PIPE
-#ifdef LATE_KEYS
     // level-0 key slices are requested here, under the last level of the forward transforms (~260 fp64
     // instructions), instead of a whole step ahead: 64 VGPRs free during the inverse transform and levels 1-2
     if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane, [&] {
@@ -279,13 +276,6 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         __builtin_amdgcn_sched_barrier(0);
     });
     else { load_keys(K, key_ip, p, lane); fft512_forward_batch<L>(x, sc_mine, table, tw, lane); }
-#else
-    if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane, [] {});
-    else fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
-#endif
-#else
-    fft512_forward_batch<L>(x, sc_mine, table, tw, lane);
-#endif
     clk.mark(1);
 #pragma unroll
     for (int l = 0; l < L; l++) {
@@ -308,22 +298,11 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         }
         __builtin_amdgcn_sched_barrier(0);
         if (l + 1 < L) load_keys(K, key_ip + (size_t)(l + 1) * 2 * 512, p, lane);
-#ifndef LATE_KEYS
-        else if (key_next) load_keys(K, key_next, p, lane);
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     // hand the partner's partial sum over
 #pragma unroll
     for (int k = 0; k < 8; k++) sc_mine[k * 64 + lane] = send[k];
-#ifdef FFT_PIPE_SEND
-    // the stores of send[k] go out under the last level's products of the remaining k (8 fp64 per k and output)
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        __builtin_amdgcn_sched_group_barrier(0x2, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-    }
-#endif
     clk.mark(2);
     __syncthreads();
     clk.mark(3);
@@ -332,11 +311,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     clk.mark(4);
     __syncthreads();
     clk.mark(5);
-#ifdef FFT_PIPE_INV
     fft512_inverse_pipe(keep, sc_mine, table, tw, lane);
-#else
-    fft512_inverse(keep, sc_mine, table, tw, lane);
-#endif
     // |v| <= 2L * N * (Bg/2) * 2^31: below 2^51 the 1.5*2^52 trick is exact (L=3, Bgbit=6: 2^48.6);
     // the Uint1 / Uint3 shapes (L=2,Bgbit=10: 2^52; L=1,Bgbit=23: 2^64) need the wide form and sit in
     // the tolerance regime, like the reference's own fp64 pipeline at those sets.
@@ -353,15 +328,9 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 // workgroup on distinct SIMDs but not those of two co-resident 2-wave workgroups (tools/ubench_placement.hip:
 // two workgroups per CU land as [2 0 1 1] waves per SIMD, one SIMD idle), so launches of 1..2 workgroups per
 // CU use this form: one 4-wave workgroup per CU = [1 1 1 1].  The two items only share the barriers.
-// -DOCC3 (with -DFFT_UNPADDED): the occupancy experiment of DESIGN.md -- one bootstrap per 2-wave workgroup at 27,140 B of
-// LDS (6 workgroups per CU) and a register budget of 168 (3 waves per SIMD); the compiler spills what does not fit.
-#ifdef OCC3
-#define BR_MIN_WAVES(items) ((items) == 1 ? 3 : 2)
-#else
-#define BR_MIN_WAVES(items) 2
-#endif
+// (Three waves per SIMD do not fit this kernel's registers: profiles/r02_e_occupancy.txt.)
 template <int L, int BGBIT, int ITEMS = 1>
-__global__ __launch_bounds__(128 * ITEMS, BR_MIN_WAVES(ITEMS)) void k_blind_rotate(BlindRotateArgs A)
+__global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs A)
 {
     constexpr int N = 1024;
     __shared__ cd scAll[ITEMS][2][kScratchSlots];
@@ -411,17 +380,13 @@ __global__ __launch_bounds__(128 * ITEMS, BR_MIN_WAVES(ITEMS)) void k_blind_rota
     constexpr size_t kStep = (size_t)2 * L * 2 * 512;        // cd elements per CMUX step
     const int nsteps = A.nsteps;
     KeyRegs K;
-#ifndef LATE_KEYS
-    if (nsteps > 0) load_keys(K, key, p, lane);
-#endif
     PhaseClock clk;
     clk.start();
     for (int i = 0; i < nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
         const DiffSource S{accL[p], at, nullptr};
-        external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, i + 1 < nsteps ? key + (size_t)(i + 1) * kStep : nullptr,
-                                        K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane, clk);
+        external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane, clk);
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
         for (int q = 0; q < 16; q++) lds_add(&accL[p][64 * q + lane], e[q]);
@@ -456,11 +421,8 @@ __global__ __launch_bounds__(128, 2) void k_external_product(const cd *bsk, cons
     const DiffSource S{nullptr, 0, src};
     const cd *key = bsk + ((size_t)key_index * 2 + p) * L * 2 * 512;
     KeyRegs K;
-#ifndef LATE_KEYS
-    load_keys(K, key, p, lane);
-#endif
     PhaseClock clk;
-    external_product_core<L, BGBIT>(S, e, key, nullptr, K, sc[p], sc[p ^ 1], twt, tw, offset, p, lane, clk);
+    external_product_core<L, BGBIT>(S, e, key, K, sc[p], sc[p ^ 1], twt, tw, offset, p, lane, clk);
     uint32_t *dst = out + (size_t)blockIdx.x * 2 * N + (size_t)p * N;
 #pragma unroll
     for (int q = 0; q < 16; q++) dst[64 * q + lane] = e[q];

@@ -184,57 +184,77 @@ __device__ __forceinline__ void external_product_core_2048(Coef coef /* j -> coe
     }
 }
 
-// Blind rotate for N = 2048 with FOUR waves per bootstrap: wave (p, h) owns half h of the root tree
-// (X^512 = +-rho) of accumulator polynomial p.  A batch of 512 PBS puts 2 workgroups on each CU, so
-// four waves per workgroup give every SIMD two waves (fp64 issue ~5.5 instead of ~8 cycles/instr).
-// Per step and wave: rebuild the 16 digit points of its polynomial, fold them to its half
-// (y = x_lo +- rho*x_hi), one 512-point forward transform, multiply with its 8+8 key slices, swap
-// the partner polynomial's share with wave (1-p, h), one 512-point inverse transform, then swap
-// halves with wave (p, 1-h) to undo the radix-2 level; wave h writes coefficient block
-// [512h, 512h+512) + {0, 1024}.  Four s_barriers per step.
-// ITEMS = 2: two bootstraps in one 8-wave workgroup = every resident wave of a CU (they share only the
-// barriers), as for k_blind_rotate<.., 4>.
-template <int BGBIT, int ITEMS = 1>
-__global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateArgs A)
+// Blind rotate for N = 2048 with FOUR waves per bootstrap (one workgroup): wave (p, h) owns half h of the root tree
+// (X^512 = +-rho) of accumulator polynomial p.  A batch of 512 PBS puts two workgroups on each CU = two waves on every
+// SIMD (fp64 issue ~5.5 instead of ~8 cycles per instruction).  Per CMUX step and wave, FOUR s_barriers:
+//
+//   extract   the digits of the wave's OWN 16 coefficients of X^a~ * acc - acc (points a in [4h, 4h+4) and a + 8, re and
+//             im): rotated operand from the polynomial's signed table in LDS, own operand from registers; fold them
+//             to both half-trees (lo +- rho*hi), keep this half-tree's four inputs, hand the other four to the sibling
+//   barrier 1
+//   forward   512-point transform of the half-tree, products with the 8 + 8 key slices: the partner polynomial's
+//             share to LDS, its own kept
+//   barrier 2
+//   gather + inverse   own + partner's share, 512-point inverse transform THROUGH THE PARTNER'S SCRATCH (what that held
+//             -- the partner's products for this wave -- was just read by this wave itself, so nothing has to be
+//             waited for: this removed a barrier); the four results the sibling's points need go to LDS
+//   barrier 3
+//   update    undo the radix-2 level for the own points, acc += round(.) in registers and in the signed table
+//   barrier 4
+//
+// LDS per bootstrap: four exchange scratches (36 KB: FFT exchanges, product hand-over, and -- in the windows where
+// their owner does not use them -- the digit and half-swap hand-overs), the signed accumulator table T[p][2N] =
+// {acc, ~acc} (32 KB: coefficient j of X^a*acc is T[(j - a) mod 2N], the reference's "negation" being the bitwise
+// complement, buffer_methods.go:152,158 -- two VALU instructions of addressing per coefficient instead of eight),
+// the mod-switched mask (2.5 KB): 70.6 KB, two workgroups per CU.
+// Measured (tools/ab_bench.py, Uint5 x 512, interleaved on one box, profiles/r03_a_uint5_steps.txt): 6.65 ms at the
+// start of round 3 -> 6.50 (own points in registers, half-swap of 4 slots, scalar twiddle loads) -> 6.43 (inverse
+// through the partner's scratch) -> 6.01 (one bootstrap per workgroup again: with four barriers the two workgroups of
+// a CU run better unsynchronised) -> this form.
+// KEYS_FIRST: the step's 16 key slices are requested at its top and held in 64 VGPRs (launches of at most one workgroup
+// per CU, where nothing else covers the L2 latency: 4.76 -> 4.34 ms at 256); with two workgroups per CU they are
+// requested where they are used, under the last level of the forward transform (6.10 vs 6.15 ms at 512).
+template <int BGBIT, bool KEYS_FIRST>
+__global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
 {
     constexpr int N = 2048;
     constexpr double r = 0.70710678118654752440;
-    __shared__ cd scAll[ITEMS][4][kScratchSlots];
-    __shared__ cd dxAll[ITEMS][4][4 * 64];        // digit-point hand-over between the two half-tree waves
-    __shared__ uint32_t accAll[ITEMS][2][N];
-    __shared__ uint16_t abarAll[ITEMS][kMaxLweDim];
-    __shared__ int btAll[ITEMS];
-    const int tid = threadIdx.x & 255, lane = tid & 63;                  // tid: thread within the item's four waves
-    const int wAll = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int w = wAll & 3, grp = ITEMS > 1 ? wAll >> 2 : 0;
+    __shared__ cd sc[4][kScratchSlots];
+    __shared__ uint32_t accT[2][2 * N];           // signed table per polynomial: T[s] = acc[s], T[N + s] = ~acc[s]
+    __shared__ uint16_t abarL[kMaxLweDim];
+    __shared__ int btL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int p = w >> 1, h = w & 1;
-    cd (&sc)[4][kScratchSlots] = scAll[grp];
-    cd (&dx)[4][4 * 64] = dxAll[grp];
-    uint32_t (&accL)[2][N] = accAll[grp];
-    uint16_t (&abarL)[kMaxLweDim] = abarAll[grp];
-    int &btL = btAll[grp];
-    const int wg_first = A.first + blockIdx.x * ITEMS;
-    if (!gate_item_live(A, wg_first)) return;       // list entries past the device-side count (kernels.hpp)
-    int item = wg_first + grp;
-    const bool live = ITEMS == 1 || (blockIdx.x * ITEMS + grp < A.batch && gate_item_live(A, item));
-    if (!live) item = wg_first;                     // the idle group recomputes the first item, stores nothing
+    const int item = A.first + blockIdx.x;
+    if (!gate_item_live(A, item)) return;           // list entries past the device-side count (kernels.hpp)
     const int n = A.n;
     const bool bad_op = gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
     LaneTwiddles tw;
     const cd *table = A.tw + (size_t)h * kTwCount1024;
     load_lane_twiddles(tw, table, lane);
     __syncthreads();
+    uint32_t *T = accT[p];
+    // Wave h owns the digit points a in [4h, 4h+4) and a + 8 of its polynomial, i.e. coefficients
+    // j0 = 256h + 64q + lane (q < 4) and j0 + 1024 (re, im of point a), j0 + 512 and j0 + 1536 (point a + 8): it
+    // extracts their digits AND applies their updates, so it keeps them in registers next to the table.
+    uint32_t own[4][4];
+    auto own_j = [&](int q, int k) { return 256 * h + 64 * q + lane + 512 * (k >> 1) + 1024 * (k & 1); };
     {
+        // acc = X^b~ * testvec (evaluator.go:116-118, buffer_methods.go:133-164)
         const int bt = btL & (2 * N - 1);
         const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {                 // wave h initialises its coefficient block
-            const int j = (q < 8 ? 64 * q + lane : 64 * (q - 8) + lane + 1024) + 512 * h;
-            const int s = (j - bt) & (2 * N - 1);
-            uint32_t v = tv[s & (N - 1)];
-            v ^= 0u - (uint32_t)((s >> 11) & 1);
-            accL[p][j] = v;
-        }
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = own_j(q, k), s = (j - bt) & (2 * N - 1);
+                uint32_t v = tv[s & (N - 1)];
+                v ^= 0u - (uint32_t)((s >> 11) & 1);      // "negation" is the bitwise complement
+                own[q][k] = v;
+                T[j] = v;
+                T[j + N] = ~v;
+            }
     }
     __syncthreads();
     constexpr uint32_t mask = (1u << BGBIT) - 1u;
@@ -243,30 +263,46 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
     const cd *key = A.bsk + (size_t)p * 2 * 1024 + (size_t)h * 8 * 64 + lane;
     constexpr size_t kStep = (size_t)2 * 2 * 1024;
     const int wpart = ((1 - p) << 1) | h;               // same half of the other polynomial
+    const int wsib = w ^ 1;                             // other half of the same polynomial
     const double sr = h ? -r : r;
+    // hand-over windows inside the exchange scratches (see the header): digits for the sibling go into the SIBLING's
+    // scratch (idle until its owner's forward transform, which reads them first); half-swap values into the scratch
+    // this wave's inverse transform has just finished with (the partner's), where the sibling finds them
+    cd *dsend = sc[wsib], *drecv = sc[w];
+    cd *ssend = sc[wpart], *srecv = sc[wpart ^ 1];
+    // both levels' derived twiddle powers, kept for the whole kernel: they are live through every step's two transforms
+    // anyway, so rebuilding them per step bought no registers at the peak
+    const TwStep ts{expand_pow_once(tw.l2), expand_pow_once(tw.l3)};
     PhaseClock clk;
     clk.start();
     for (int i = 0; i < A.nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         const cd *kp = key + (size_t)i * kStep;
-        // Both half-trees need all 16 digit points of the polynomial (y_h[a] = x[a] +- rho*x[a+8]).  Wave h
-        // extracts the points of a in [4h, 4h+4) only, forms both combinations, keeps its own and hands the
-        // other half-tree's through LDS: half the decomposition work per wave for 4 slots each way.
+        const cd *kKeep = kp + (size_t)(p ? 1 : 0) * 1024;
+        const cd *kSend = kp + (size_t)(p ? 0 : 1) * 1024;
+        cd kk[8], ks[8];
+        if constexpr (KEYS_FIRST) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { kk[k] = kKeep[k * 64]; ks[k] = kSend[k * 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         cd keep[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int j = 256 * h + 64 * q + lane;
-            const uint32_t d0 = diff_coeff_2048(accL[p], at, nullptr, j) + A.offset;
-            const uint32_t d1 = diff_coeff_2048(accL[p], at, nullptr, j + 1024) + A.offset;
-            const uint32_t d2 = diff_coeff_2048(accL[p], at, nullptr, j + 512) + A.offset;
-            const uint32_t d3 = diff_coeff_2048(accL[p], at, nullptr, j + 512 + 1024) + A.offset;
-            const cd lo = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
-            const cd hi = cd{(double)((int)((d2 >> shift) & mask) - half), (double)((int)((d3 >> shift) & mask) - half)};
+            int dg[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {            // k = 0: re of point a, 1: im of a, 2: re of a + 8, 3: im of a + 8
+                const uint32_t v = T[(own_j(q, k) - at) & (2 * N - 1)];
+                const uint32_t d = v - own[q][k] + A.offset;         // X^at*acc - acc (evaluator.go:93-96), + offset
+                dg[k] = (int)((d >> shift) & mask) - half;           // decomposer.go:60-65
+            }
+            // rho*(a + ib) = ((a - b) + i(a + b))/sqrt2, a -+ b formed on the integer digits (exact: |digit| < 2^21);
             // sr = +-1/sqrt2 by half-tree: y_h[a] = lo + (+-rho)*hi is kept, lo - (+-rho)*hi goes to the other wave
             // (written as FMAs with a uniform sign: a select between the two sums ends up in scratch memory)
-            const cd t = cd{hi.re - hi.im, hi.re + hi.im};
-            keep[q] = cd{fma(sr, t.re, lo.re), fma(sr, t.im, lo.im)};
-            dx[w][q * 64 + lane] = cd{fma(-sr, t.re, lo.re), fma(-sr, t.im, lo.im)};
+            const double lo_re = (double)dg[0], lo_im = (double)dg[1];
+            const double t_re = (double)(dg[2] - dg[3]), t_im = (double)(dg[2] + dg[3]);
+            keep[q] = cd{fma(sr, t_re, lo_re), fma(sr, t_im, lo_im)};
+            dsend[q * 64 + lane] = cd{fma(-sr, t_re, lo_re), fma(-sr, t_im, lo_im)};
         }
         clk.mark(0);
         __syncthreads();
@@ -274,19 +310,17 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
         cd y[8];
         if (h == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) { y[q] = keep[q]; y[4 + q] = dx[w ^ 1][q * 64 + lane]; }
+            for (int q = 0; q < 4; q++) { y[q] = keep[q]; y[4 + q] = drecv[q * 64 + lane]; }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) { y[4 + q] = keep[q]; y[q] = dx[w ^ 1][q * 64 + lane]; }
+            for (int q = 0; q < 4; q++) { y[4 + q] = keep[q]; y[q] = drecv[q * 64 + lane]; }
         }
-        const TwStep ts{expand_pow(tw.l2), expand_pow(tw.l3)};         // shared by this step's forward and inverse
-        fft512_forward(y, sc[w], table, tw, ts, lane);                 // (-28 VALU per step: 6.84 -> 6.68 ms at x512)
-        const cd *kKeep = kp + (size_t)(p ? 1 : 0) * 1024;
-        const cd *kSend = kp + (size_t)(p ? 0 : 1) * 1024;
+        fft512_forward(y, sc[w], table, tw, ts, lane);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            sc[w][k * 64 + lane] = cmul(y[k], kSend[k * 64]);
-            y[k] = cmul(y[k], kKeep[k * 64]);
+            if constexpr (!KEYS_FIRST) { kk[k] = kKeep[k * 64]; ks[k] = kSend[k * 64]; }
+            sc[w][k * 64 + lane] = cmul(y[k], ks[k]);
+            y[k] = cmul(y[k], kk[k]);
         }
         clk.mark(2);
         __syncthreads();
@@ -294,44 +328,46 @@ __global__ __launch_bounds__(256 * ITEMS) void k_blind_rotate_2048(BlindRotateAr
 #pragma unroll
         for (int k = 0; k < 8; k++) y[k] = y[k] + sc[wpart][k * 64 + lane];
         clk.mark(4);
-        __syncthreads();
-        clk.mark(5);
-        fft512_inverse(y, sc[w], table, tw, ts, lane);  // table carries conj(c1)/1024
+        fft512_inverse(y, sc[wpart], table, tw, ts, lane);  // table carries conj(c1)/1024
+        // undo the radix-2 level, x[a] = y0[a] + y1[a], x[a+8] = conj(rho)(y0[a] - y1[a]), for the wave's OWN points
+        // a = 4h + q: it sends the sibling's four values and receives its own four -- half the traffic of exchanging
+        // all eight, and both waves do the same work
+        cd mine[4];                         // (uniform branches, not selects: those end up in scratch memory)
+        if (h == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) sc[w][k * 64 + lane] = y[k];
+            for (int q = 0; q < 4; q++) { ssend[q * 64 + lane] = y[4 + q]; mine[q] = y[q]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { ssend[q * 64 + lane] = y[q]; mine[q] = y[4 + q]; }
+        }
         clk.mark(6);
         __syncthreads();
         clk.mark(7);
-        uint32_t e[16];
 #pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const cd o = sc[w ^ 1][a * 64 + lane];
-            cd x;
-            if (h == 0) x = y[a] + o;                                            // x[a]   = y0 + y1
-            else { const cd dl = o - y[a]; x = cd{(dl.re + dl.im) * r, (dl.im - dl.re) * r}; }   // x[a+8] = conj(rho)(y0 - y1)
-            e[a] = round_to_torus_wide(x.re);
-            e[a + 8] = round_to_torus_wide(x.im);
-        }
+        for (int q = 0; q < 4; q++) {
+            const cd o = srecv[q * 64 + lane], m = mine[q];
+            const cd sm = m + o, dl = m - o;                               // m - o = (-1)^h (y0 - y1)
+            const double z[4] = {sm.re, sm.im, (dl.re + dl.im) * sr, (dl.im - dl.re) * sr};
 #pragma unroll
-        for (int a = 0; a < 8; a++) {
-            lds_add(&accL[p][64 * a + lane + 512 * h], e[a]);
-            lds_add(&accL[p][64 * a + lane + 512 * h + 1024], e[a + 8]);
+            for (int k = 0; k < 4; k++) {
+                own[q][k] += round_to_torus_wide(z[k]);                    // acc += e (evaluator.go:102-105)
+                T[own_j(q, k)] = own[q][k];
+                T[own_j(q, k) + N] = ~own[q][k];
+            }
         }
         clk.mark(8);
         __syncthreads();
         clk.mark(9);
     }
-    if (!live) return;
 #ifdef PHASE_TRACE
     clk.store(A.out + (size_t)item * 2 * N, w, lane);
     return;
 #endif
     uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int j = (q < 8 ? 64 * q + lane : 64 * (q - 8) + lane + 1024) + 512 * h;
-        out[j] = accL[p][j];
-    }
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[own_j(q, k)] = own[q][k];
     report_bad_op(A, bad_op, tid);
 }
 

@@ -99,40 +99,8 @@ __device__ __forceinline__ QuadLane quad_lane(int lane) { return {lane, lane >> 
 
 // NB independent forward transforms advanced level by level through one scratch (in-order DS argument of
 // negacyclic_fft.hpp: fft512_forward_batch).  x[t][a] = y[64a + lane] in, spectrum order out.
-// Timing ablations (tools/build_variant.sh -DQUAD_ABL_*): results are garbage when any is set.
-#ifdef QUAD_ABL_NOXCHG_F
-#define QUAD_XF(stmt)
-#else
-#define QUAD_XF(stmt) _Pragma("unroll") stmt
-#endif
-#ifdef QUAD_ABL_NOXCHG_I
-#define QUAD_XI(stmt)
-#else
-#define QUAD_XI(stmt) _Pragma("unroll") stmt
-#endif
-#ifdef QUAD_ABL_NOBAR
-#define QUAD_SYNC()
-#else
-#define QUAD_SYNC() __syncthreads()
-#endif
-#ifdef QUAD_ABL_HOTKEY            /* every step reads step 0's key: L1/L2-hot */
-#define QUAD_KEYSTEP(i) 0
-#else
-#define QUAD_KEYSTEP(i) (i)
-#endif
-#ifdef QUAD_PRIO
-#define QUAD_PRIO_HI() TFHE_PRIO(3)
-#define QUAD_PRIO_LO() TFHE_PRIO(0)
-#else
-#define QUAD_PRIO_HI()
-#define QUAD_PRIO_LO()
-#endif
-#ifdef QUAD_STAGGER
-#define QUAD_PIN() __builtin_amdgcn_sched_barrier(0)
-#else
-#define QUAD_PIN()
-#endif
-
+// (Timing ablations of this kernel -- no exchanges, no barriers, cache-hot key, static priorities -- are recorded in
+// profiles/r02_a_quad_ablation.txt; their switches are no longer compiled.)
 template <int NB>
 __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw,
                                                      const QuadLane q)
@@ -142,39 +110,36 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
 #pragma unroll
         for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], T[a]);
         dft4<1>(x[t]);
-        QUAD_PRIO_HI();
-        QUAD_XF(for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];)
+        #pragma unroll
+        for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];
         wave_lds_order();
-        QUAD_XF(for (int b = 0; b < 4; b++) x[t][b] = sc[64 * q.hi + 16 * b + (q.lane & 15)];)
+        #pragma unroll
+        for (int b = 0; b < 4; b++) x[t][b] = sc[64 * q.hi + 16 * b + (q.lane & 15)];
         wave_lds_order();
-        QUAD_PRIO_LO();
-        QUAD_PIN();
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
 #pragma unroll
         for (int b = 1; b < 4; b++) x[t][b] = cmul(x[t][b], tw.w[0][b - 1]);
         dft4<1>(x[t]);
-        QUAD_PRIO_HI();
-        QUAD_XF(for (int mp = 0; mp < 4; mp++) sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo] = x[t][mp];)
+        #pragma unroll
+        for (int mp = 0; mp < 4; mp++) sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo] = x[t][mp];
         wave_lds_order();
-        QUAD_XF(for (int c = 0; c < 4; c++) x[t][c] = sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo];)
+        #pragma unroll
+        for (int c = 0; c < 4; c++) x[t][c] = sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo];
         wave_lds_order();
-        QUAD_PRIO_LO();
-        QUAD_PIN();
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
 #pragma unroll
         for (int c = 1; c < 4; c++) x[t][c] = cmul(x[t][c], tw.w[1][c - 1]);
         dft4<1>(x[t]);
-        QUAD_PRIO_HI();
-        QUAD_XF(for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)] = x[t][mpp];)
+        #pragma unroll
+        for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)] = x[t][mpp];
         wave_lds_order();
-        QUAD_XF(for (int d = 0; d < 4; d++) x[t][d] = sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)];)
+        #pragma unroll
+        for (int d = 0; d < 4; d++) x[t][d] = sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)];
         wave_lds_order();
-        QUAD_PRIO_LO();
-        QUAD_PIN();
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
@@ -185,10 +150,8 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
 }
 
 // Software-pipelined form (see fft512_forward_batch_pipe): transform t's exchange is issued inside transform t+1's
-// arithmetic, one DS instruction per QUAD_PIPE_VALU VALU instructions.
-#ifndef QUAD_PIPE_VALU
-#define QUAD_PIPE_VALU 6
-#endif
+// arithmetic, one DS instruction per kQuadPipeValu VALU instructions.
+constexpr int kQuadPipeValu = 6;
 template <int NB>
 __device__ __forceinline__ void fft256_forward_batch_pipe(cd (&x)[NB][4], cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw,
                                                           const QuadLane q)
@@ -229,12 +192,12 @@ __device__ __forceinline__ void fft256_forward_batch_pipe(cd (&x)[NB][4], cd *sc
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, QUAD_PIPE_VALU, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, kQuadPipeValu, 0);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, QUAD_PIPE_VALU, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, kQuadPipeValu, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -262,23 +225,29 @@ __device__ __forceinline__ void fft256_inverse(cd (&x)[4], cd *sc, const cd *__r
     dft4<-1>(x);
 #pragma unroll
     for (int d = 1; d < 4; d++) x[d] = cmulc(x[d], tw.w[2][d - 1]);
-    QUAD_XI(for (int d = 0; d < 4; d++) sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)] = x[d];)
+    #pragma unroll
+    for (int d = 0; d < 4; d++) sc[64 * q.hi + 16 * d + 4 * q.mid + ((d + q.lo) & 3)] = x[d];
     wave_lds_order();
-    QUAD_XI(for (int mpp = 0; mpp < 4; mpp++) x[mpp] = sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)];)
+    #pragma unroll
+    for (int mpp = 0; mpp < 4; mpp++) x[mpp] = sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)];
     wave_lds_order();
     dft4<-1>(x);
 #pragma unroll
     for (int c = 1; c < 4; c++) x[c] = cmulc(x[c], tw.w[1][c - 1]);
-    QUAD_XI(for (int c = 0; c < 4; c++) sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo] = x[c];)
+    #pragma unroll
+    for (int c = 0; c < 4; c++) sc[64 * q.hi + 16 * q.mid + 4 * ((c + q.mid) & 3) + q.lo] = x[c];
     wave_lds_order();
-    QUAD_XI(for (int mp = 0; mp < 4; mp++) x[mp] = sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo];)
+    #pragma unroll
+    for (int mp = 0; mp < 4; mp++) x[mp] = sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo];
     wave_lds_order();
     dft4<-1>(x);
 #pragma unroll
     for (int b = 1; b < 4; b++) x[b] = cmulc(x[b], tw.w[0][b - 1]);
-    QUAD_XI(for (int b = 0; b < 4; b++) sc[64 * q.hi + 16 * b + (q.lane & 15)] = x[b];)
+    #pragma unroll
+    for (int b = 0; b < 4; b++) sc[64 * q.hi + 16 * b + (q.lane & 15)] = x[b];
     wave_lds_order();
-    QUAD_XI(for (int m = 0; m < 4; m++) x[m] = sc[64 * m + q.lane];)
+    #pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = sc[64 * m + q.lane];
     wave_lds_order();
     dft4<-1>(x);
 #pragma unroll
@@ -304,12 +273,7 @@ __device__ __forceinline__ void load_quad_keys(QuadKeys &K, const cd *__restrict
 // WPS = waves per SIMD the launch shape needs (register budget 512 / WPS).  KD = key levels fetched at the top
 // of a step: L (all of them, 32 L VGPRs, for one wave per SIMD where nothing else hides the L2 latency) or 1
 // (level 0 at the top, level l+1 under the products of level l, as k_blind_rotate does).
-#ifndef QUAD_KD1
-#define QUAD_KD_DEFAULT (WPS == 1 ? L : 1)
-#else
-#define QUAD_KD_DEFAULT 1
-#endif
-template <int L, int BGBIT, int ITEMS, int WPS, int KD = QUAD_KD_DEFAULT>
+template <int L, int BGBIT, int ITEMS, int WPS, int KD = (WPS == 1 ? L : 1)>
 __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRotateArgs A)
 {
     constexpr int N = 1024, W = 4 * ITEMS;
@@ -371,7 +335,7 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
         // this step's key slices: issued first, they land under the decomposition and the forward transforms
         QuadKeys K[KD];
 #pragma unroll
-        for (int l = 0; l < KD; l++) load_quad_keys(K[l], key + (size_t)QUAD_KEYSTEP(i) * kStep + (size_t)l * 512, p, lane);
+        for (int l = 0; l < KD; l++) load_quad_keys(K[l], key + (size_t)i * kStep + (size_t)l * 512, p, lane);
         __builtin_amdgcn_sched_barrier(0);
         // d = X^at*acc - acc (evaluator.go:93-96,122-126), decomposed (decomposer.go:55-66) and folded to this
         // half-tree: y_h[j] = dig(z_j) + (-1)^h rho dig(z_{j+256}), z_j = d_j + i d_{j+512}.  rho*(a+ib) =
@@ -396,12 +360,8 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
                 x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
             }
         }
-#ifdef QUAD_PIPE
         if constexpr (L > 1) fft256_forward_batch_pipe<L>(x, sc, T, tw, q);
         else fft256_forward_batch<L>(x, sc, T, tw, q);
-#else
-        fft256_forward_batch<L>(x, sc, T, tw, q);
-#endif
         cd keep[4], send[4];
 #pragma unroll
         for (int l = 0; l < L; l++) {
@@ -417,24 +377,26 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
                 }
             }
             if (KD == 1 && l + 1 < L) {
-                // anchor the products before the registers are refilled (see external_product_core)
+                // anchor the products before the registers are refilled (see external_product_core).  NOT volatile: in a
+                // kernel body (no __restrict__ scope around it) a volatile asm counts as a possible store to anything and
+                // de-scalarises every wave-uniform twiddle load of the loop (negacyclic_fft.hpp, expand_pow_once)
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    asm volatile("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
+                    asm("" : "+v"(keep[k].re), "+v"(keep[k].im), "+v"(send[k].re), "+v"(send[k].im));
                 __builtin_amdgcn_sched_barrier(0);
-                load_quad_keys(K[0], key + (size_t)QUAD_KEYSTEP(i) * kStep + (size_t)(l + 1) * 512, p, lane);
+                load_quad_keys(K[0], key + (size_t)i * kStep + (size_t)(l + 1) * 512, p, lane);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) sendAll[w][k * 64 + lane] = send[k];
-        QUAD_SYNC();
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++) keep[k] = keep[k] + sendAll[partner][k * 64 + lane];
         fft256_inverse(keep, sc, T, tw, q);
 #pragma unroll
         for (int k = 0; k < 4; k++) swapAll[w][k * 64 + lane] = keep[k];
-        QUAD_SYNC();
+        __syncthreads();
         // undo the radix-2 level: z_j = y0 + y1, z_{j+256} = conj(rho)(y0 - y1) (the 1/2 is in the inverse's scale);
         // own - other = (-1)^h (y0 - y1).  acc += round(.) on the private copy (evaluator.go:102-105).
 #pragma unroll
@@ -477,9 +439,7 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
 // is one signed table of 3N words per polynomial, T[s] = acc[s], ~acc[s - N], acc[s - 2N], shared by the polynomial's
 // four waves: the decomposition reads X^a*acc - acc through two base addresses and immediate offsets, each wave
 // updates its quarter of the coefficients after the half swap, and a third barrier publishes the table.
-#ifndef OCT_KEY_GAP
-#define OCT_KEY_GAP 8
-#endif
+constexpr int kOctKeyGap = 8;        // VALU instructions between two key loads of a step's prologue
 template <int L, int BGBIT, int LB, int NL>
 __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint32_t *Tp /* signed table of polynomial p */,
                                             int at, double sr, int lane, int p,
@@ -493,9 +453,6 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
     QuadKeys K[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) load_quad_keys(K[l], key_iph + (size_t)(LB + l) * 512, p, lane);
-#ifdef OCT_KEYS_FIRST
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     cd x[NL][4];
     // X^at * acc - acc straight from the signed table (T[s] = acc[s], ~acc[s - N], acc[s - 2N] for s in [0, N), [N, 2N),
     // [2N, 3N)): two base addresses per step, every coefficient an immediate offset from them
@@ -513,16 +470,14 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
             x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
         }
     }
-#ifndef OCT_KEYS_FIRST
     // the gather first, then the key loads trickle out between the digit arithmetic: eight waves issuing 8 NL loads
     // back to back queue behind each other at the CU's one address path and start the decomposition late
     __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
 #pragma unroll
     for (int t = 0; t < 8 * NL; t++) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, OCT_KEY_GAP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kOctKeyGap, 0);
     }
-#endif
     tr.mark(0);
     if constexpr (NL > 1) fft256_forward_batch_pipe<NL>(x, sc, T, tw, q);
     else fft256_forward_batch<NL>(x, sc, T, tw, q);

@@ -210,11 +210,7 @@ __global__ __launch_bounds__(512) void k_keyswitch_mfma(const uint4 *__restrict_
                 v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
                 v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
                 const int row = m0 + wm * 32 * MI + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-#ifdef KS_ABL_STORE
-                if ((l & 3) == 0 && word < n1 && row < live_items) out[(size_t)row * n1 + word] = 0u - (v + fix);
-#else
                 if ((l & 3) == 0 && word < n1 && row < live_items) atomicAdd(&out[(size_t)row * n1 + word], 0u - (v + fix));
-#endif
             }
         }
 }

@@ -74,22 +74,17 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 #define TFHE_PRIO(n) __builtin_amdgcn_s_setprio(n)
 // LDS-exchange scheduling (r02; A/B on one box, tools/ab_bench.py): the exchanges' DS instructions are spread
 // through the arithmetic with sched_group_barrier instead of being issued in bursts -- the waves of these kernels
-// spend ~20 % of their cycles stalled on the LDS instruction queue (SQ_WAIT_INST_LDS), a burst of ds_write_b128
+// spent ~20 % of their cycles stalled on the LDS instruction queue (SQ_WAIT_INST_LDS), a burst of ds_write_b128
 // fills it.  k_blind_rotate<3,6,4> x1024: 6.34 -> 6.11 ms; k_blind_rotate_2048 x512: 6.98 -> 6.79 ms;
-// k_blind_rotate_quad x128: 3.19 -> 3.10 ms.  -DFFT_NO_PIPE restores the burst form (the A/B baseline).
-#ifndef FFT_NO_PIPE
-#define FFT_PIPE
-#define FFT_PIPE1
-#define QUAD_PIPE
-// k_blind_rotate: level-0 key slices requested under the last level of the forward transforms instead of a whole
-// step ahead (64 VGPRs free for most of the step), which lets the inverse transform's stores be spread as well
-// without spilling: 6.08 -> 6.02 ms (each alone: +-0).
-#define LATE_KEYS
-#define FFT_PIPE_INV
+// k_blind_rotate_quad x128: 3.19 -> 3.10 ms.  The burst forms and the other rejected variants (unpadded scratch,
+// spread hand-over stores, static priorities) are recorded in profiles/ and no longer compiled.
+constexpr int kPipeValu = 10;       // batched forward transforms: VALU instructions per DS instruction (5 / 8 / 10: 6.15 / 6.13 / 6.11 ms)
+#ifdef PIPE1V
+constexpr int kPipe1Valu = PIPE1V;
+#else
+constexpr int kPipe1Valu = 3;
 #endif
-#ifndef FFT_PIPE_VALU
-#define FFT_PIPE_VALU 10
-#endif
+//       // single transforms (N = 2048 blind rotate): VALU instructions between two stores
 
 __device__ __forceinline__ void wave_lds_order()
 {
@@ -102,22 +97,11 @@ __device__ __forceinline__ void wave_lds_order()
 // stride both exchange patterns are conflict-free for ds_write_b128 (8 contiguous lanes ->
 // 8 contiguous slots) and ds_read_b128 (the four 16-lane service groups each touch 16
 // distinct slot residues mod 16).
-#ifdef FFT_UNPADDED
-// Unpadded variant (512 slots = 8 KiB per wave, for the occupancy experiment -DOCC3): the same two exchanges with
-// swizzled slots instead of padded rows; every ds_write_b128 pass hits 8 slot residues mod 8 and every ds_read_b128
-// service group 16 residues mod 16, in both directions (brute-force checked).
-constexpr int kScratchSlots = 512;
-#define SL1W(r) (64 * (r) + 8 * ((hi + (((r) >> 1) & 1)) & 7) + lo)            /* (reg r; lane hi,lo) exchange-1 store side */
-#define SL1R(r) (64 * hi + 8 * (((r) + ((hi >> 1) & 1)) & 7) + lo)              /* exchange-1 load side */
-#define SL2W(r) (64 * hi + 8 * (((r) + (hi >> 1)) & 7) + ((lo + (r)) & 7))      /* exchange-2 store side */
-#define SL2R(r) (64 * hi + 8 * ((lo + (hi >> 1)) & 7) + (((r) + lo) & 7))       /* exchange-2 load side */
-#else
 constexpr int kScratchSlots = 8 * 72;
 #define SL1W(r) (72 * (r) + lane)
 #define SL1R(r) (72 * hi + 8 * (r) + lo)
 #define SL2W(r) (72 * hi + 9 * (r) + lo)
 #define SL2R(r) (72 * hi + 9 * lo + (r))
-#endif
 
 // Twiddle table layout (built on the host in long double, tfhe_hip.cpp):
 //   [0..7]                 level-1 pre-twists      c1[a]  = zeta^(64 a)          (wave-uniform)
@@ -171,6 +155,18 @@ template <bool CONJ> __device__ __forceinline__ void twist_pow(cd (&x)[8], const
 struct TwAll {
     cd w3, w5, w6, w7;
 };
+// The derived powers for a kernel that keeps them for its whole life (built once, outside the CMUX loop): no asm.
+// (expand_pow below keeps the rebuild INSIDE a loop with a volatile empty asm; such an asm counts as a store to
+// anything for LLVM's "is this uniform load clobbered" test unless it sits in a function with __restrict__ pointer
+// parameters, and then turns every wave-uniform twiddle load after it from s_load into global_load + s_waitcnt vmcnt --
+// which is what the N = 2048 blind rotate suffered from until round 3.)
+__device__ __forceinline__ TwAll expand_pow_once(const TwPow &t)
+{
+    TwAll a;
+    a.w3 = cmul(t.w1, t.w2); a.w5 = cmul(t.w1, t.w4); a.w6 = cmul(t.w2, t.w4);
+    a.w7 = cmul(a.w3, t.w4);
+    return a;
+}
 __device__ __forceinline__ TwAll expand_pow(const TwPow &t)
 {
     cd w1 = t.w1;
@@ -239,28 +235,20 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
 }
 
 // The same transforms with the derived powers supplied by the caller (TwStep), no rebuild inside.
-// Single transforms (one forward, one inverse per wave and step: the N = 2048 blind rotate).  With -DFFT_PIPE1
-// every exchange's stores are issued one by one under the tail of the arithmetic that produces them
-// (sched_group_barrier) instead of as a burst of eight after it.
-#ifdef FFT_PIPE1
+// Single transforms (one forward, one inverse per wave and step: the N = 2048 blind rotate): every exchange's
+// stores are issued one by one under the tail of the arithmetic that produces them (sched_group_barrier)
+// instead of as a burst of eight after it.
 #define FFT_MIX1(first)                                                           \
     do {                                                                          \
         __builtin_amdgcn_sched_group_barrier(0x2, first, 0);                      \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; k_++) {                        \
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                    \
-            __builtin_amdgcn_sched_group_barrier(0x2, FFT_PIPE1_VALU, 0);         \
+            __builtin_amdgcn_sched_group_barrier(0x2, kPipe1Valu, 0);             \
         }                                                                         \
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                        \
         __builtin_amdgcn_sched_barrier(0);                                        \
     } while (0)
 #define FFT_MIX1_BEGIN() __builtin_amdgcn_sched_barrier(0)
-#ifndef FFT_PIPE1_VALU
-#define FFT_PIPE1_VALU 3
-#endif
-#else
-#define FFT_MIX1(first)
-#define FFT_MIX1_BEGIN()
-#endif
 __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                const LaneTwiddles &tw, const TwStep &ts, int lane)
 {
@@ -362,7 +350,7 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
     }
 }
 
-// Software-pipelined form of fft512_forward_batch (experiment, -DFFT_PIPE): transform t's exchange (8 stores + 8
+// Software-pipelined form of fft512_forward_batch: transform t's exchange (8 stores + 8
 // loads) is issued INSIDE transform t+1's arithmetic, one DS instruction per few fp64 instructions
 // (sched_group_barrier), instead of one burst of 24 + 24 after all three transforms' arithmetic.  Rationale:
 // PMC shows the waves of k_blind_rotate spend ~20 % of their cycles stalled on the LDS instruction queue
@@ -388,16 +376,16 @@ __device__ __forceinline__ void fft512_forward_batch_pipe(cd (&x)[NB][8], cd *sc
         for (int c = 0; c < 8; c++) x[t][c] = sc[SL2R(c)];
         wave_lds_order();
     };
-    auto mix = [&]() {          // the region just written: 1 DS op per FFT_PIPE_VALU VALU ops, stores first
+    auto mix = [&]() {          // the region just written: 1 DS op per kPipeValu VALU ops, stores first
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, FFT_PIPE_VALU, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, kPipeValu, 0);
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x2, FFT_PIPE_VALU, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, kPipeValu, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -460,7 +448,7 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
 }
 
 // fft512_inverse with each exchange's stores issued as soon as their value is final (one ds_write_b128 per twisted
-// output, under the remaining twists) instead of in one burst of eight; same arithmetic.  (-DFFT_PIPE_INV)
+// output, under the remaining twists) instead of in one burst of eight; same arithmetic.
 __device__ __forceinline__ void fft512_inverse_pipe(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                     const LaneTwiddles &tw, int lane)
 {
@@ -518,7 +506,7 @@ __device__ __forceinline__ uint32_t round_to_torus_small(double v)
 __device__ __forceinline__ uint32_t round_to_torus_wide(double v)
 {
     double q = v + 29014219670751100192948224.0;      // 1.5 * 2^84
-    asm volatile("" : "+v"(q));
+    asm("" : "+v"(q));
     q -= 29014219670751100192948224.0;
     return round_to_torus_small(v - q);
 }

@@ -9,6 +9,7 @@
 #include <sys/random.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +57,7 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }      // locals are released on every early-return path
+    bool fits(size_t bytes) const { return bytes <= cap; }
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return TFHE_OK;
@@ -86,8 +88,16 @@ struct tfhe_ctx {
     // host-pointer batches longer than one slab: transfers of slab s+1 / s-1 overlap the kernels of slab s
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     hipEvent_t pipe_ev[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};      // [in, done, out][buffer]
-    hipStream_t last_dev_stream = nullptr;      // stream of the most recent _dev call (tfhe_ctx_sync waits for it too)
-    bool last_dev_stream_set = false;
+    // One event per caller stream that "_dev" calls were enqueued on, re-recorded behind every such call: tfhe_ctx_sync
+    // and tfhe_ctx_destroy wait on the EVENTS (context-owned, valid whatever became of the stream), never on a stream
+    // handle the caller may have destroyed.  The handle value is only a lookup key.
+    struct DevStreamMark { hipStream_t key; hipEvent_t ev; };
+    std::vector<DevStreamMark> dev_marks;
+    // Set once a "_dev" call has been enqueued on a capturing stream: the addresses of the intermediate buffers are
+    // then recorded in the caller's hipGraph, so growing (= freeing and re-allocating) them would leave the graph
+    // pointing at freed memory.  From then on a call that needs larger buffers fails with TFHE_E_INVALID instead
+    // (tfhe_ctx_reserve before capturing; TFHE_OPT_FROZEN = 0 once the graphs are gone).
+    bool frozen = false;
     int oct_limit = 0;          // ... and of up to this many the eight-wave kernel (one bootstrap per CU)
     int quad_limit = 0;         // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
     hipStream_t stream = nullptr;
@@ -202,6 +212,45 @@ bool stream_capturing(hipStream_t st)
 {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
+// Intermediate buffers of the batch paths (s_trlwe, s_onehot, s_idx, s_plan, s_t0..s_t3) are grow-only, and growing
+// means hipFree + hipMalloc: an implicit device synchronisation, illegal while `st` is being captured, and fatal for
+// a hipGraph that already recorded the old address (tfhe_ctx::frozen).  In both cases the call is refused with a
+// message that names the remedy instead of a raw HIP error or, worse, a graph replaying into freed memory.
+int grow(tfhe_ctx *c, DevBuf &b, size_t bytes, hipStream_t st, const char *what)
+{
+    if (b.fits(bytes)) return TFHE_OK;
+    const bool cap = stream_capturing(st);
+    if (cap || c->frozen)
+        return fail(TFHE_E_INVALID,
+                    "the context's %s buffer would have to grow from %zu to %zu bytes %s: call tfhe_ctx_reserve(ctx, max_batch, "
+                    "with_mux) for the largest batch BEFORE capturing%s",
+                    what, b.cap, bytes,
+                    cap ? "while the stream is being captured into a hipGraph (no allocation is possible there)"
+                        : "but a captured hipGraph holds its current address (the context is frozen)",
+                    cap ? "" : ", or clear TFHE_OPT_FROZEN once every such graph is destroyed");
+    return b.reserve(bytes);
+}
+
+// Behind every "_dev" call: re-record the context-owned event of the caller's stream (see tfhe_ctx::dev_marks).
+int mark_dev_stream(tfhe_ctx *c, hipStream_t st)
+{
+    if (stream_capturing(st)) return TFHE_OK;             // an event record would become a node of the caller's graph
+    constexpr size_t kMaxMarks = 8;
+    for (auto &m : c->dev_marks)
+        if (m.key == st) { HIP_TRY(hipEventRecord(m.ev, st)); return TFHE_OK; }
+    tfhe_ctx::DevStreamMark m{st, nullptr};
+    if (c->dev_marks.size() >= kMaxMarks) {               // recycle the oldest mark once its work is done
+        m.ev = c->dev_marks.front().ev;
+        HIP_TRY(hipEventSynchronize(m.ev));
+        c->dev_marks.erase(c->dev_marks.begin());
+    } else {
+        HIP_TRY(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+    }
+    c->dev_marks.push_back(m);
+    HIP_TRY(hipEventRecord(m.ev, st));
+    return TFHE_OK;
 }
 
 int timing_begin(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t *stop)
@@ -333,7 +382,7 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     const bool mfma = c->kskB.p && c->ks_mfma_min > 0 && B >= c->ks_mfma_min;
     if (mfma) {                 // the one-hot matrix of one chunk (a no-op after reserve_scratch / the first call)
         const int Bc = B < kKsMfmaChunk ? B : kKsMfmaChunk, MpadMax = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
-        int rc = c->s_onehot.reserve((size_t)ks_mfma_pieces(c->P) * MpadMax * sizeof(uint4));
+        int rc = grow(c, c->s_onehot, (size_t)ks_mfma_pieces(c->P) * MpadMax * sizeof(uint4), st, "one-hot digit");
         if (rc) return rc;
     }
     hipEvent_t stop;
@@ -351,9 +400,6 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
             const int Mpad = (M + kKsGroup - 1) / kKsGroup * kKsGroup, m_groups = Mpad / kKsGroup;
             // K ranges: as many as give every CU at most ONE workgroup (that is all a CU holds: no second, partial round)
             int parts = c->num_cus / (m_groups * n_groups);
-#ifdef KS_XCD_PARTS
-            parts = KS_XCD_PARTS;
-#endif
             if (parts < 1) parts = 1;
             if (parts > pairs_total) parts = pairs_total;
             const int per_part = (pairs_total + parts - 1) / parts;
@@ -436,20 +482,21 @@ int pipe_items(const tfhe_ctx *c) { return 16 * launch_items(c); }
 
 // Scratch for slabs of up to `items` bootstraps (mux: with the three-pass MUX form).  hipMalloc is not allowed
 // while a stream is being captured: callers that capture run one call (or tfhe_ctx_reserve) beforehand.
-int reserve_scratch(tfhe_ctx *c, int items, bool mux)
+int reserve_scratch(tfhe_ctx *c, int items, bool mux, hipStream_t st)
 {
     const int S = items < slab_items(c) ? items : slab_items(c);
     const size_t trl = (size_t)S * 2 * c->P.N * sizeof(uint32_t), rows = (size_t)S * (c->P.n + 1) * sizeof(uint32_t);
     int rc;
-    if ((rc = c->s_trlwe.reserve(mux ? 2 * trl : trl))) return rc;
+    if ((rc = grow(c, c->s_trlwe, mux ? 2 * trl : trl, st, "TRLWE accumulator"))) return rc;
     if (c->kskB.p) {            // one-hot digit matrix of the matrix-core key switch (one chunk; launch_keyswitch)
         const int Bc = S < kKsMfmaChunk ? S : kKsMfmaChunk, Mpad = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
-        if ((rc = c->s_onehot.reserve((size_t)ks_mfma_pieces(c->P) * Mpad * sizeof(uint4)))) return rc;
+        if ((rc = grow(c, c->s_onehot, (size_t)ks_mfma_pieces(c->P) * Mpad * sizeof(uint4), st, "one-hot digit"))) return rc;
     }
     if (mux) {
         const int nb = (S + kPlanBlock - 1) / kPlanBlock;
-        if ((rc = c->s_idx.reserve((size_t)S * sizeof(int))) || (rc = c->s_plan.reserve((size_t)(2 * nb + 2) * sizeof(int))) ||
-            (rc = c->s_t0.reserve(rows)) || (rc = c->s_t1.reserve(rows)))
+        if ((rc = grow(c, c->s_idx, (size_t)S * sizeof(int), st, "MUX list")) ||
+            (rc = grow(c, c->s_plan, (size_t)(2 * nb + 2) * sizeof(int), st, "MUX plan")) ||
+            (rc = grow(c, c->s_t0, rows, st, "MUX temporary")) || (rc = grow(c, c->s_t1, rows, st, "MUX temporary")))
             return rc;
     }
     return TFHE_OK;
@@ -470,7 +517,7 @@ int gate_batch_device(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const u
     const bool mux = d_c && (d_ops || op_uniform == TFHE_OP_MUX);
     if (!d_ops && op_uniform == TFHE_OP_MUX && !d_c) return fail(TFHE_E_INVALID, "MUX needs the third operand");
     int rc;
-    if ((rc = reserve_scratch(c, B, mux))) return rc;
+    if ((rc = reserve_scratch(c, B, mux, st))) return rc;
     const size_t n1 = (size_t)c->P.n + 1, trlw = (size_t)2 * c->P.N;
     const int slab = slab_items(c);
     for (int base = 0; base < B; base += slab) {
@@ -519,7 +566,7 @@ int bootstrap_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, in
                      hipStream_t st)
 {
     int rc;
-    if ((rc = reserve_scratch(c, B, false))) return rc;
+    if ((rc = reserve_scratch(c, B, false, st))) return rc;
     const size_t n1 = (size_t)c->P.n + 1, trlw = (size_t)2 * c->P.N;
     const int slab = slab_items(c);
     for (int base = 0; base < B; base += slab) {
@@ -542,7 +589,8 @@ int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t 
     const size_t N = 2048, n1 = (size_t)c->P.n + 1;
     const size_t accw = (size_t)ext * B * 2 * N;
     int rc;
-    if ((rc = c->s_t2.reserve(2 * accw * sizeof(uint32_t))) || (rc = c->s_t3.reserve((size_t)B * n1 * sizeof(uint32_t)))) return rc;
+    if ((rc = grow(c, c->s_t2, 2 * accw * sizeof(uint32_t), st, "extended accumulator")) ||
+        (rc = grow(c, c->s_t3, (size_t)B * n1 * sizeof(uint32_t), st, "mod-switched sample"))) return rc;
     uint32_t *acc[2] = {c->s_t2.as<uint32_t>(), c->s_t2.as<uint32_t>() + accw};
     ExtendedArgs a{};
     a.bsk = c->bsk.as<cd>(); a.tw = c->tw.as<cd>();
@@ -577,7 +625,7 @@ int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const 
     if ((rc = c->s_in0.reserve(2 * slab_rows)) || (rc = c->s_in1.reserve(2 * slab_rows)) || (rc = c->s_out.reserve(2 * slab_rows))) return rc;
     if (cc && (rc = c->s_in2.reserve(2 * slab_rows))) return rc;
     if (ops && (rc = c->s_ops.reserve(2 * (size_t)S))) return rc;
-    if ((rc = reserve_scratch(c, S, cc && (ops || op_uniform == TFHE_OP_MUX)))) return rc;
+    if ((rc = reserve_scratch(c, S, cc && (ops || op_uniform == TFHE_OP_MUX), c->stream))) return rc;
     if (!c->h2d_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
@@ -677,15 +725,10 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
         c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    {
-        // tuning override for A/B measurements (tools/): TFHE_QUAD_MAX=0 keeps every launch on the two-wave kernel
-        const char *e = getenv("TFHE_QUAD_MAX");
-        c->quad_limit = e ? atoi(e) : c->num_cus;
-        e = getenv("TFHE_OCT_MAX");
-        c->oct_limit = e ? atoi(e) : c->num_cus;
-        e = getenv("TFHE_KS_MFMA_MIN");             // 0 = never (the vector-ALU key-switch kernels for every batch)
-        c->ks_mfma_min = e ? atoi(e) : kKsMfmaMinDefault;
-    }
+    // kernel-dispatch limits: defaults here, tfhe_ctx_set_option for measurements and tests -- never the environment
+    c->quad_limit = c->num_cus;
+    c->oct_limit = c->num_cus;
+    c->ks_mfma_min = kKsMfmaMinDefault;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
@@ -714,8 +757,10 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     if (!c) return TFHE_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &m : c->dev_marks) { (void)hipEventSynchronize(m.ev); (void)hipEventDestroy(m.ev); }      // "_dev" work on caller streams
+    c->dev_marks.clear();
     for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->status, &c->s_plan, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
-                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3})
+                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3, &c->kskB, &c->s_onehot})
         b->release();
     for (auto &pair : c->ev)
         for (auto &e : pair) if (e) (void)hipEventDestroy(e);
@@ -743,8 +788,41 @@ int tfhe_ctx_sync(tfhe_ctx *c)
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->last_dev_stream_set && !stream_capturing(c->last_dev_stream)) HIP_TRY(hipStreamSynchronize(c->last_dev_stream));
+    for (auto &m : c->dev_marks) HIP_TRY(hipEventSynchronize(m.ev));
     return check_status(c);
+}
+
+int tfhe_ctx_set_option(tfhe_ctx *c, int option, int value)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    switch (option) {
+    case TFHE_OPT_QUAD_MAX: c->quad_limit = value < 0 ? c->num_cus : value; return TFHE_OK;
+    case TFHE_OPT_OCT_MAX: c->oct_limit = value < 0 ? c->num_cus : value; return TFHE_OK;
+    case TFHE_OPT_KS_MFMA_MIN:
+        c->ks_mfma_min = value < 0 ? kKsMfmaMinDefault : value;
+        if (c->ks_mfma_min > 0 && c->have_ksk && !c->kskB.p) {      // the byte-column key copy was skipped at load time
+            if ((rc = make_mfma_ksk(c, c->stream))) return rc;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return TFHE_OK;
+    case TFHE_OPT_FROZEN: c->frozen = value != 0; return TFHE_OK;
+    default: return fail(TFHE_E_INVALID, "unknown option %d", option);
+    }
+}
+
+int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
+{
+    if (!c || !value) return fail(TFHE_E_INVALID, "null argument");
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    switch (option) {
+    case TFHE_OPT_QUAD_MAX: *value = c->quad_limit; return TFHE_OK;
+    case TFHE_OPT_OCT_MAX: *value = c->oct_limit; return TFHE_OK;
+    case TFHE_OPT_KS_MFMA_MIN: *value = c->ks_mfma_min; return TFHE_OK;
+    case TFHE_OPT_FROZEN: *value = c->frozen ? 1 : 0; return TFHE_OK;
+    default: return fail(TFHE_E_INVALID, "unknown option %d", option);
+    }
 }
 
 int tfhe_ctx_reserve(tfhe_ctx *c, int max_batch, int with_mux)
@@ -753,7 +831,7 @@ int tfhe_ctx_reserve(tfhe_ctx *c, int max_batch, int with_mux)
     if (rc) return rc;
     if (max_batch < 0) return fail(TFHE_E_INVALID, "bad batch size");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    return reserve_scratch(c, max_batch, with_mux != 0);
+    return reserve_scratch(c, max_batch, with_mux != 0, c->stream);
 }
 
 int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
@@ -893,14 +971,67 @@ int tfhe_keygen_cloud_seeded(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1
 }
 
 // ---- device-layout key blobs (replication across GPUs, save / restore) ------------------------------------
+// A blob = a 64-byte header + the device layout of the key.  The header names what the payload is (magic, layout
+// version of this library, which key, the parameter set, the payload length) and carries a checksum of those fields,
+// so a blob of another parameter set, another key kind, another layout version -- or a truncated buffer -- is
+// rejected (TFHE_E_INVALID) instead of being installed as garbage.
 namespace {
+constexpr uint64_t kKeyBlobMagic = 0x0159454B45484654ull;       // "TFHEKEY\x01", little-endian
+constexpr uint32_t kKeyLayoutVersion = 3;                        // bump whenever a device key layout changes
+struct KeyBlobHeader {
+    uint64_t magic;
+    uint32_t layout, which;
+    int32_t params[7];
+    uint32_t n1p;
+    uint64_t payload_bytes;
+    uint64_t check;              // FNV-1a over everything above
+};
+static_assert(sizeof(KeyBlobHeader) == 64, "the key blob header is 64 bytes");
+
 size_t ksk_device_bytes(const tfhe_ctx *c) { return (ksk_rows_packed(c->P) + 1) * (size_t)c->n1p * sizeof(uint32_t); }
+size_t key_payload_bytes(const tfhe_ctx *c, int which) { return which == 0 ? bsk_elems(c->P) * sizeof(cd) : ksk_device_bytes(c); }
+
+uint64_t header_check(const KeyBlobHeader &h)
+{
+    uint64_t x = 0xcbf29ce484222325ull;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&h);
+    for (size_t i = 0; i < offsetof(KeyBlobHeader, check); i++) { x ^= p[i]; x *= 0x100000001b3ull; }
+    return x;
+}
+
+KeyBlobHeader make_header(const tfhe_ctx *c, int which)
+{
+    KeyBlobHeader h{};
+    h.magic = kKeyBlobMagic; h.layout = kKeyLayoutVersion; h.which = (uint32_t)which;
+    const int32_t pp[7] = {c->P.n, c->P.N, c->P.Nbit, c->P.L, c->P.Bgbit, c->P.basebit, c->P.t};
+    memcpy(h.params, pp, sizeof pp);
+    h.n1p = (uint32_t)c->n1p;
+    h.payload_bytes = key_payload_bytes(c, which);
+    h.check = header_check(h);
+    return h;
+}
+
+int check_header(const tfhe_ctx *c, int which, const KeyBlobHeader &h, size_t bytes)
+{
+    if (bytes < sizeof(KeyBlobHeader)) return fail(TFHE_E_INVALID, "key blob of %zu bytes is shorter than its header", bytes);
+    if (h.magic != kKeyBlobMagic || h.check != header_check(h)) return fail(TFHE_E_INVALID, "not a key blob of this library (bad magic or header checksum)");
+    if (h.layout != kKeyLayoutVersion)
+        return fail(TFHE_E_INVALID, "key blob has device-layout version %u, this library reads version %u: export it again with this build", h.layout, kKeyLayoutVersion);
+    if ((int)h.which != which) return fail(TFHE_E_INVALID, "key blob holds key %u, asked to install it as key %d (0 = bootstrapping, 1 = key-switching)", h.which, which);
+    const KeyBlobHeader want = make_header(c, which);
+    if (memcmp(h.params, want.params, sizeof h.params) || h.n1p != want.n1p)
+        return fail(TFHE_E_INVALID, "key blob was exported for another parameter set (n=%d N=%d L=%d Bgbit=%d basebit=%d t=%d), the context has n=%d N=%d L=%d Bgbit=%d basebit=%d t=%d",
+                    h.params[0], h.params[1], h.params[3], h.params[4], h.params[5], h.params[6], c->P.n, c->P.N, c->P.L, c->P.Bgbit, c->P.basebit, c->P.t);
+    if (h.payload_bytes != want.payload_bytes || bytes != sizeof(KeyBlobHeader) + want.payload_bytes)
+        return fail(TFHE_E_INVALID, "key blob length %zu does not match header + payload = %zu bytes", bytes, sizeof(KeyBlobHeader) + (size_t)want.payload_bytes);
+    return TFHE_OK;
+}
 }
 
 int tfhe_key_size(tfhe_ctx *c, int which, size_t *bytes)
 {
     if (!c || !bytes || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
-    *bytes = which == 0 ? bsk_elems(c->P) * sizeof(cd) : ksk_device_bytes(c);
+    *bytes = sizeof(KeyBlobHeader) + key_payload_bytes(c, which);
     return TFHE_OK;
 }
 
@@ -911,29 +1042,35 @@ int tfhe_key_export_dev(tfhe_ctx *c, int which, void *d_dst, void *stream)
     if (!d_dst || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (which == 0 ? !c->have_bsk : !c->have_ksk) return fail(TFHE_E_NOKEY, "key not loaded");
-    size_t bytes;
-    tfhe_key_size(c, which, &bytes);
-    HIP_TRY(hipMemcpyAsync(d_dst, which == 0 ? c->bsk.p : c->ksk.p, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    const KeyBlobHeader h = make_header(c, which);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(d_dst, &h, sizeof h, hipMemcpyHostToDevice, st));          // pageable source: copied before the call returns
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_dst) + sizeof h, which == 0 ? c->bsk.p : c->ksk.p, h.payload_bytes,
+                           hipMemcpyDeviceToDevice, st));
     return TFHE_OK;
 }
 
-int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, void *stream)
+int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, size_t bytes, void *stream)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!d_src || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    size_t bytes;
-    tfhe_key_size(c, which, &bytes);
     hipStream_t st = (hipStream_t)stream;
+    KeyBlobHeader h{};
+    if (bytes < sizeof h) return fail(TFHE_E_INVALID, "key blob of %zu bytes is shorter than its header", bytes);
+    HIP_TRY(hipMemcpyAsync(&h, d_src, sizeof h, hipMemcpyDeviceToHost, st));           // the one synchronisation of an import:
+    HIP_TRY(hipStreamSynchronize(st));                                                 // the header is checked on the host
+    if ((rc = check_header(c, which, h, bytes))) return rc;
+    const char *payload = static_cast<const char *>(d_src) + sizeof h;
     if (which == 0) {
-        if ((rc = c->bsk.reserve(bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->bsk.p, d_src, bytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = c->bsk.reserve(h.payload_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->bsk.p, payload, h.payload_bytes, hipMemcpyDeviceToDevice, st));
         if ((rc = make_quad_key(c, st))) return rc;
         c->have_bsk = true;
     } else {
-        if ((rc = c->ksk.reserve(bytes))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->ksk.p, d_src, bytes, hipMemcpyDeviceToDevice, st));
+        if ((rc = c->ksk.reserve(h.payload_bytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->ksk.p, payload, h.payload_bytes, hipMemcpyDeviceToDevice, st));
         if ((rc = make_mfma_ksk(c, st))) return rc;
         c->have_ksk = true;
     }
@@ -948,24 +1085,27 @@ int tfhe_key_export(tfhe_ctx *c, int which, void *dst)
     if (!dst || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (which == 0 ? !c->have_bsk : !c->have_ksk) return fail(TFHE_E_NOKEY, "key not loaded");
-    size_t bytes;
-    tfhe_key_size(c, which, &bytes);
-    HIP_TRY(hipMemcpyAsync(dst, which == 0 ? c->bsk.p : c->ksk.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    const KeyBlobHeader h = make_header(c, which);
+    memcpy(dst, &h, sizeof h);
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(dst) + sizeof h, which == 0 ? c->bsk.p : c->ksk.p, h.payload_bytes,
+                           hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;
 }
 
-int tfhe_key_import(tfhe_ctx *c, int which, const void *src)
+int tfhe_key_import(tfhe_ctx *c, int which, const void *src, size_t bytes)
 {
     int rc = check_ctx(c);
     if (rc) return rc;
     if (!src || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    size_t bytes;
-    tfhe_key_size(c, which, &bytes);
+    KeyBlobHeader h{};
+    if (bytes < sizeof h) return fail(TFHE_E_INVALID, "key blob of %zu bytes is shorter than its header", bytes);
+    memcpy(&h, src, sizeof h);
+    if ((rc = check_header(c, which, h, bytes))) return rc;
     DevBuf &dstbuf = which == 0 ? c->bsk : c->ksk;
-    if ((rc = dstbuf.reserve(bytes))) return rc;
-    HIP_TRY(hipMemcpyAsync(dstbuf.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if ((rc = dstbuf.reserve(h.payload_bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(dstbuf.p, static_cast<const char *>(src) + sizeof h, h.payload_bytes, hipMemcpyHostToDevice, c->stream));
     if ((rc = which == 0 ? make_quad_key(c, c->stream) : make_mfma_ksk(c, c->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     (which == 0 ? c->have_bsk : c->have_ksk) = true;
@@ -986,7 +1126,13 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
     if (rc) return rc;                                              \
     std::lock_guard<std::recursive_mutex> lk(c->mu);                \
     hipStream_t st = pick(c, stream);                               \
-    c->last_dev_stream = st; c->last_dev_stream_set = true
+    if (stream_capturing(st)) c->frozen = true      /* the graph will hold the intermediate buffers' addresses */
+// ... and behind the enqueued work the stream's event is re-recorded (tfhe_ctx_sync / tfhe_ctx_destroy wait on it)
+#define DEV_RETURN(expr)                                            \
+    do {                                                            \
+        rc = (expr);                                                \
+        return rc ? rc : mark_dev_stream(c, st);                    \
+    } while (0)
 
 int tfhe_blind_rotate_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,
                                 uint32_t *d_out, int B, int nsteps, void *stream)
@@ -995,14 +1141,14 @@ int tfhe_blind_rotate_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_
     if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     RotateJob j;
     j.in0 = d_in; j.tv = d_tv; j.tv_per_item = tv_per_item; j.out = d_out; j.B = B; j.nsteps = nsteps;
-    return launch_blind_rotate(c, j, st);
+    DEV_RETURN(launch_blind_rotate(c, j, st));
 }
 
 int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *c, const uint32_t *d_in, uint32_t *d_out, int B, void *stream)
 {
     DEV_PROLOGUE();
     if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
-    return launch_keyswitch(c, d_in, d_out, B, nullptr, st);
+    DEV_RETURN(launch_keyswitch(c, d_in, d_out, B, nullptr, st));
 }
 
 int tfhe_bootstrap_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,
@@ -1012,7 +1158,7 @@ int tfhe_bootstrap_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *
     if (B < 0 || (B > 0 && (!d_in || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
-    return bootstrap_device(c, d_in, d_tv, tv_per_item, d_out, B, st);
+    DEV_RETURN(bootstrap_device(c, d_in, d_tv, tv_per_item, d_out, B, st));
 }
 
 int tfhe_bootstrap_extended_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_lut, int lut_per_item, int ext,
@@ -1022,7 +1168,7 @@ int tfhe_bootstrap_extended_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const u
     if (B < 0 || (B > 0 && (!d_in || !d_lut || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
-    return bootstrap_extended_device(c, d_in, d_lut, lut_per_item, ext, d_out, B, st);
+    DEV_RETURN(bootstrap_extended_device(c, d_in, d_lut, lut_per_item, ext, d_out, B, st));
 }
 
 int tfhe_gate_batch_dev(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a, const uint32_t *d_b,
@@ -1032,9 +1178,10 @@ int tfhe_gate_batch_dev(tfhe_ctx *c, const uint8_t *d_ops, int op_uniform, const
     if (B < 0 || (B > 0 && (!d_a || !d_b || !d_out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
-    return gate_batch_device(c, d_ops, op_uniform, d_a, d_b, d_c, d_out, B, st);
+    DEV_RETURN(gate_batch_device(c, d_ops, op_uniform, d_a, d_b, d_c, d_out, B, st));
 }
 #undef DEV_PROLOGUE
+#undef DEV_RETURN
 
 // ---- host-pointer variants: stage, run, copy back, synchronise -----------------------
 
@@ -1048,7 +1195,7 @@ int tfhe_blind_rotate_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv,
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
     const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
-    if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_trlwe.reserve(trl)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
+    if ((rc = c->s_in0.reserve(inb)) || (rc = grow(c, c->s_trlwe, trl, c->stream, "TRLWE accumulator")) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
     if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
     {
@@ -1070,7 +1217,7 @@ int tfhe_extract_keyswitch_batch(tfhe_ctx *c, const uint32_t *in, uint32_t *out,
     if (B == 0) return TFHE_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t outb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
-    if ((rc = c->s_out.reserve(outb)) || (rc = c->s_trlwe.reserve(trl))) return rc;
+    if ((rc = c->s_out.reserve(outb)) || (rc = grow(c, c->s_trlwe, trl, c->stream, "TRLWE accumulator"))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
     if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), c->s_out.as<uint32_t>(), B, nullptr, c->stream))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->s_out.p, outb, hipMemcpyDeviceToHost, c->stream));
@@ -1160,7 +1307,7 @@ int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, 
     if (B == 0) return TFHE_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t trl = (size_t)B * 2 * c->P.N * 4;
-    if ((rc = c->s_trlwe.reserve(trl)) || (rc = c->s_t0.reserve(trl))) return rc;
+    if ((rc = grow(c, c->s_trlwe, trl, c->stream, "TRLWE accumulator")) || (rc = grow(c, c->s_t0, trl, c->stream, "temporary"))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
     launch_external_product(c->shape, c->bsk.as<cd>(), c->tw.as<cd>(), key_index, c->s_trlwe.as<uint32_t>(),
                             c->s_t0.as<uint32_t>(), c->offset, B, c->stream);
@@ -1178,7 +1325,7 @@ int tfhe_to_fourier_batch(tfhe_ctx *c, const uint32_t *polys, double *spectra, i
     if (P == 0) return TFHE_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
-    if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
+    if ((rc = grow(c, c->s_t0, pb, c->stream, "temporary")) || (rc = grow(c, c->s_t1, sb, c->stream, "temporary"))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t0.p, polys, pb, hipMemcpyHostToDevice, c->stream));
     if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_to_fourier, dim3(P), dim3(64), 0, c->stream, c->s_t0.as<uint32_t>(), c->s_t1.as<double>(),
@@ -1203,7 +1350,7 @@ int tfhe_to_poly_batch(tfhe_ctx *c, const double *spectra, uint32_t *polys, int 
     if (P == 0) return TFHE_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t pb = (size_t)P * c->P.N * 4, sb = (size_t)P * c->P.N * 8;
-    if ((rc = c->s_t0.reserve(pb)) || (rc = c->s_t1.reserve(sb))) return rc;
+    if ((rc = grow(c, c->s_t0, pb, c->stream, "temporary")) || (rc = grow(c, c->s_t1, sb, c->stream, "temporary"))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_t1.p, spectra, sb, hipMemcpyHostToDevice, c->stream));
     if (shape_is_1024(c->shape))
         hipLaunchKernelGGL(k_to_poly, dim3(P), dim3(64), 0, c->stream, c->s_t1.as<double>(), c->s_t0.as<uint32_t>(),

@@ -82,16 +82,38 @@ int tfhe_device_count(int *count);
 int tfhe_ctx_create(const tfhe_params *params, int device_id, tfhe_ctx **out);
 int tfhe_ctx_destroy(tfhe_ctx *ctx);
 int tfhe_ctx_params(const tfhe_ctx *ctx, tfhe_params *out);
-/* Waits for the context's private stream and for the stream of its most recent "_dev" call, then reports
- * (TFHE_E_INVALID) and clears anything the kernels recorded since the last call: an op code outside
- * TFHE_OP_NAND..TFHE_OP_MUX, or a MUX item without a third operand, in a tfhe_gate_batch_dev whose op codes the
- * host never sees.  Such items ran as plain bootstraps of their first operand. */
+/* Waits for the context's private stream and for everything "_dev" calls of this context have enqueued so far on
+ * ANY caller stream (the context records an event of its own behind each such call -- it never touches a caller's
+ * stream handle again, so streams may be destroyed freely), then reports (TFHE_E_INVALID) and clears anything the
+ * kernels recorded since the last call: an op code outside TFHE_OP_NAND..TFHE_OP_MUX, or a MUX item without a third
+ * operand, in a tfhe_gate_batch_dev whose op codes the host never sees.  Such items ran as plain bootstraps of their
+ * first operand.  tfhe_ctx_destroy waits for the same events before it frees anything. */
 int tfhe_ctx_sync(tfhe_ctx *ctx);
 /* Sizes the context's intermediate device buffers for "_dev" batches of up to max_batch items (with_mux: for gate
  * batches that may contain MUX items) so that later calls allocate nothing -- required before capturing "_dev"
  * calls into a hipGraph.  Work is issued in slabs of 64 co-resident launches (65,536 bootstraps at N = 1024), so the
- * buffers stop growing there: 0.54 GB, 1.07 GB with MUX. */
+ * buffers stop growing there: 0.54 GB, 1.07 GB with MUX.
+ * Growth rules: the buffers are grow-only and growing re-allocates.  A "_dev" call that would have to grow one while
+ * its stream is being captured returns TFHE_E_INVALID (message names this function) instead of a HIP error; and once
+ * any "_dev" call HAS been captured the context is FROZEN -- the graph holds the buffers' addresses -- so every later
+ * call of any kind that needs larger buffers returns TFHE_E_INVALID rather than freeing memory a graph replay would
+ * touch.  Clear TFHE_OPT_FROZEN after destroying the graphs to allow growth again. */
 int tfhe_ctx_reserve(tfhe_ctx *ctx, int max_batch, int with_mux);
+
+/* Per-context options.  Kernel dispatch is a function of the parameters and the batch size only; these exist for
+ * measurements (tools/) and tests, and are deliberately NOT read from the environment: a service must not change
+ * kernels because of a stray variable.  value < 0 restores the default of the three limits. */
+enum {
+    TFHE_OPT_QUAD_MAX = 1,     /* N = 1024: launches of up to this many bootstraps use the small-batch (four-/eight-wave)
+                                  kernels; default = number of CUs; 0 = always the two-wave kernel                       */
+    TFHE_OPT_OCT_MAX = 2,      /* ... and of those, up to this many the eight-wave kernel; default = number of CUs       */
+    TFHE_OPT_KS_MFMA_MIN = 3,  /* batches of at least this many ciphertexts use the matrix-core key switch where the key
+                                  shape has one (default 1); 0 = never (the vector-ALU kernels)                          */
+    TFHE_OPT_FROZEN = 4        /* 1 while a captured hipGraph may hold the intermediate buffers' addresses (set by the
+                                  library, see tfhe_ctx_reserve); the caller clears it once those graphs are destroyed    */
+};
+int tfhe_ctx_set_option(tfhe_ctx *ctx, int option, int value);
+int tfhe_ctx_get_option(tfhe_ctx *ctx, int option, int *value);
 
 /* CloudKey.BootstrappingKey (cloudkey.go:16-21, []*trgsw.TRGSWLv1FFT, trgsw.go:60-68),
  * flattened by the shim to [n][2L][2][N] float64: row r < L multiplies the digits of A,
@@ -126,18 +148,21 @@ int tfhe_keygen_cloud(tfhe_ctx *ctx, const uint32_t *s0, const uint32_t *s1, dou
 
 /* The loaded keys as opaque device-layout blobs: CloudKey (cloudkey.go:16-21) has no serialised form in the
  * reference; this is the engine's.  which: 0 = bootstrapping key (wave-native spectra, same byte count as the
- * reference's [n][2L][2][N] float64), 1 = key-switching key (packed, zero rows dropped).  Export copies the blob to
- * caller-owned DEVICE memory of tfhe_key_size bytes, import installs one (and derives what the engine derives
- * at load time) -- both enqueue on `stream`.  A blob is only meaningful to a context with the SAME parameters and
- * the same library build.  Uses: replicate a key from GPU 0 to the other GPUs of a node with one RCCL broadcast
- * per key instead of N uploads / regenerations, or park it in host memory between runs. */
+ * reference's [n][2L][2][N] float64), 1 = key-switching key (packed, zero rows dropped).  A blob is a 64-byte header
+ * (magic, device-layout version of the library, which key, the parameter set, payload length, header checksum)
+ * followed by the payload; tfhe_key_size = header + payload.  Export copies the blob to caller-owned DEVICE memory of
+ * tfhe_key_size bytes (enqueued on `stream`); import takes the blob and ITS LENGTH, checks the header against the
+ * context -- another parameter set, the other key, a blob of a library with a different device layout, or a short /
+ * long buffer return TFHE_E_INVALID and install nothing -- then installs it (and derives what the engine derives at
+ * load time) on `stream`; import synchronises `stream` once, to read the header.  Uses: replicate a key from GPU 0 to
+ * the other GPUs of a node with one RCCL broadcast per key instead of N uploads / regenerations, or
+ * park it in host memory / on disk between runs. */
 int tfhe_key_size(tfhe_ctx *ctx, int which, size_t *bytes);
 int tfhe_key_export_dev(tfhe_ctx *ctx, int which, void *d_dst, void *stream);
-int tfhe_key_import_dev(tfhe_ctx *ctx, int which, const void *d_src, void *stream);
-/* The same blobs through HOST memory (tfhe_key_size bytes): persist a GPU-generated cloud key, or hand it to another
- * process; synchronous. */
+int tfhe_key_import_dev(tfhe_ctx *ctx, int which, const void *d_src, size_t bytes, void *stream);
+/* The same blobs through HOST memory: persist a GPU-generated cloud key, or hand it to another process; synchronous. */
 int tfhe_key_export(tfhe_ctx *ctx, int which, void *dst);
-int tfhe_key_import(tfhe_ctx *ctx, int which, const void *src);
+int tfhe_key_import(tfhe_ctx *ctx, int which, const void *src, size_t bytes);
 
 /* Evaluator.BootstrapAssign / BootstrapLUTAssign over a batch (evaluator.go:139-148,
  * programmable_bootstrap.go:93-115; batch fan-out trgsw.go:234-252).

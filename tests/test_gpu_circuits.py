@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rand_u32
+from conftest import gpu_params, rand_u32
 
 pytestmark = pytest.mark.gpu
 
@@ -245,3 +245,74 @@ def test_mixed_stream_per_gpu_share_131072(oracle, keys128, ck128, pkg):
     ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops[sample], np.ascontiguousarray(a[sample]),
                                np.ascontiguousarray(b[sample]), np.ascontiguousarray(c[sample]))
     assert np.array_equal(out[sample], ref)
+
+
+def test_growth_during_or_after_capture_is_refused_not_undefined(pkg, keys_small):
+    """include/tfhe_hip.h, tfhe_ctx_reserve: the intermediate buffers are grow-only and growing re-allocates.  A "_dev"
+    call that would have to grow one while its stream is being captured must fail with a message naming
+    tfhe_ctx_reserve (not a raw HIP error), and once a call HAS been captured the context is frozen: a later, larger
+    call is refused as well (a re-allocation would leave the graph replaying into freed memory) until the caller
+    clears the flag.  A context reserved up front captures and replays."""
+    import torch
+    k = keys_small
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    ctx = ck.ctx
+    a = torch.from_numpy(k.enc([0, 1] * 32).view(np.int32)).cuda()
+    b = torch.from_numpy(k.enc([1, 1] * 32).view(np.int32)).cuda()
+    out = torch.zeros_like(a)
+    ctx.reserve(4)                                     # too small for the 64-gate batch below
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(pkg.TfheError, match="tfhe_ctx_reserve"):
+        with torch.cuda.graph(graph, stream=side):
+            ctx.gate_batch_dev("NAND", a, b, None, out, side)
+    torch.cuda.synchronize()
+    assert ctx.get_option("frozen") == 1               # a call was issued on a capturing stream
+    with pytest.raises(pkg.TfheError, match="frozen"):
+        ctx.gate_batch_dev("NAND", a, b, None, out)    # un-captured, but would re-allocate what a graph may hold
+    ctx.set_option("frozen", 0)
+    ctx.gate_batch_dev("NAND", a, b, None, out)        # grows now
+    ctx.sync()
+    want = ~(np.array([0, 1] * 32, bool) & np.array([1, 1] * 32, bool))
+    assert np.array_equal(k.dec(out.cpu().numpy().view(np.uint32)), want)
+    # reserved up front: captures, replays, and stays usable for smaller batches afterwards
+    ctx.reserve(64)
+    out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        ctx.gate_batch_dev("NAND", a, b, None, out, side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(k.dec(out.cpu().numpy().view(np.uint32)), want)
+    ctx.gate_batch_dev("AND", a[:8].contiguous(), b[:8].contiguous(), None, out[:8])
+    ctx.sync()
+    with pytest.raises(pkg.TfheError, match="frozen"):
+        big = torch.cat([a, a, a])
+        ctx.gate_batch_dev("NAND", big, torch.cat([b, b, b]), None, torch.zeros_like(big))
+    del graph
+    ck.close()
+
+
+def test_sync_waits_for_every_stream_even_destroyed_ones(pkg, keys_small):
+    """tfhe_ctx_sync waits on context-owned events recorded behind each "_dev" call, on whichever stream it was issued;
+    the caller may have destroyed the stream since (the library keeps no stream handles)."""
+    import torch
+    k = keys_small
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    bits = [0, 1, 1, 0] * 8
+    a = torch.from_numpy(k.enc(bits).view(np.int32)).cuda()
+    b = torch.from_numpy(k.enc([1] * 32).view(np.int32)).cuda()
+    ck.ctx.reserve(32)
+    outs = []
+    torch.cuda.synchronize()
+    for i in range(3):
+        st = torch.cuda.Stream()
+        o = torch.zeros_like(a)
+        ck.ctx.gate_batch_dev("AND", a, b, None, o, st)
+        outs.append(o)
+        del st                                          # torch returns the stream to its pool; we never touch it again
+    ck.ctx.sync()                                       # no torch synchronisation: the context's own events
+    for o in outs:
+        assert np.array_equal(k.dec(o.cpu().numpy().view(np.uint32)), np.array(bits, bool))
+    ck.close()

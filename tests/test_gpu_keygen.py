@@ -107,7 +107,7 @@ def test_default_seed_is_os_entropy(oracle, pkg):
     for seed in (None, None, (5 << 64) | 9, (5 << 64) | 9, 9):
         ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=seed)
         assert list(oracle.decrypt_bools(p, s0, ck.ctx.gate_batch("NAND", a, b))) == [True, True, True, False]
-        blobs.append(ck.ctx.key_export_dev(0).cpu().numpy().view(np.uint32).copy())   # the bootstrapping key (no padding words)
+        blobs.append(ck.ctx.key_export_dev(0).cpu().numpy()[64:].view(np.uint32).copy())   # the bootstrapping key behind the 64-byte blob header (no padding words)
         ck.close()
     assert (blobs[0] == blobs[1]).mean() < 0.01                   # OS entropy: unrelated keys
     assert np.array_equal(blobs[2], blobs[3])                     # fixed seed: reproducible
@@ -134,9 +134,25 @@ def test_key_blobs_through_host_memory(oracle, pkg, tmp_path):
         for which in (0, 1):
             ck2.ctx.key_import(which, np.load(tmp_path / f"{name}_{which}.npy"))
         assert np.array_equal(ck2.ctx.bootstrap_batch(cts, lut), want), name
-        with pytest.raises(ValueError):
-            ck2.ctx.key_import(0, np.zeros(16, np.uint8))
+        # what the header is for: a short buffer, a blob of the other key, a damaged header and a blob of another
+        # parameter set are all refused (TFHE_E_INVALID) and install nothing
+        good = np.load(tmp_path / f"{name}_0.npy")
+        assert good.size == ck2.ctx.key_size(0) and bytes(good[:7]) == b"TFHEKEY"
+        bad_param = good.copy(); bad_param[16] ^= 1                      # first parameter word, checksum no longer matches
+        for bad in (np.zeros(16, np.uint8), good[:-1], np.load(tmp_path / f"{name}_1.npy"), bad_param, np.zeros_like(good)):
+            with pytest.raises(pkg.TfheError):
+                ck2.ctx.key_import(0, bad)
+        assert np.array_equal(ck2.ctx.bootstrap_batch(cts, lut), want), name     # still the good key
         ck2.close()
+    # a blob of one parameter set offered to a context of another (same ring, other LWE dimension)
+    p_a, p_b = oracle.params("128").small(10), oracle.params("128").small(12)
+    rng = oracle.rng(0x7F4E0047)
+    s0, s1 = oracle.keygen_secret(p_a, rng)
+    ck_a = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p_a), s0, s1, p_a.alpha_lv0, p_a.alpha_lv1, seed=78)
+    ck_b = pkg.CloudKey(gpu_params(pkg, p_b))
+    with pytest.raises(pkg.TfheError, match="another parameter set"):
+        ck_b.ctx.key_import(0, ck_a.ctx.key_export(0))
+    ck_a.close(); ck_b.close()
 
 
 def _wave_blob_to_reference_spectra(blob, n, L):
@@ -170,8 +186,8 @@ def test_keygen_noise_statistics(oracle, pkg):
     rng = oracle.rng(0x7F4E0044)
     s0, s1 = oracle.keygen_secret(p, rng)
     ck = pkg.CloudKey.NewCloudKey(gpu_params(pkg, p), s0, s1, p.alpha_lv0, p.alpha_lv1, seed=2024)
-    ksk = ck.ctx.key_export_dev(1).cpu().numpy().view(np.uint32)
-    bskb = ck.ctx.key_export_dev(0).cpu().numpy()
+    ksk = ck.ctx.key_export_dev(1).cpu().numpy()[64:].view(np.uint32)          # payloads behind the 64-byte blob headers
+    bskb = ck.ctx.key_export_dev(0).cpu().numpy()[64:]
     ck.close()
     # ---- key-switching key: packed rows [N*t*(base-1) + 1][n1p], row (i, j, k-1) encrypts k*s1[i]*2^(32-(j+1)*basebit) under s0
     n1p = (p.n + 1 + 3) & ~3

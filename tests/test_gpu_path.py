@@ -106,9 +106,9 @@ def test_extract_keyswitch_tiled_kernel_bit_exact(oracle, request, which, B):
 
 
 @pytest.mark.parametrize("which", ["small", "80", "128", "uint2"])
-def test_matrix_core_keyswitch_equals_vector_kernels(pkg, oracle, request, which, monkeypatch):
+def test_matrix_core_keyswitch_equals_vector_kernels(pkg, oracle, request, which):
     # csrc/keyswitch_mfma.hpp (the default for the base-4 sets: exact int8 matrix product over byte columns) against the
-    # vector-ALU kernels of csrc/kernels.hpp (TFHE_KS_MFMA_MIN=0: per-ciphertext gather below 32, the tiled kernel above)
+    # vector-ALU kernels of csrc/kernels.hpp (option ks_mfma_min = 0: per-ciphertext gather below 32, the tiled kernel above)
     # on the same key and inputs, bit for bit, across the tile edges (256-row groups, 1,024-row chunks) -- and both
     # against the oracle on a sample.
     # "uint2": base 16 (one coefficient's 16 candidate rows per 16-K piece), N = 512, a random key of reduced dimension.
@@ -118,10 +118,10 @@ def test_matrix_core_keyswitch_equals_vector_kernels(pkg, oracle, request, which
         k = SimpleNamespace(p=p2, ksk=rand_u32(np.random.RandomState(29), (p2.N * p2.t * (1 << p2.basebit), p2.n + 1)))
     else:
         k = request.getfixturevalue({"small": "keys_small", "80": "keys80", "128": "keys128"}[which])
-    monkeypatch.setenv("TFHE_KS_MFMA_MIN", "0")
     ckv = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
-    monkeypatch.delenv("TFHE_KS_MFMA_MIN")
+    ckv.ctx.set_option("ks_mfma_min", 0)
     ckm = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
+    assert ckm.ctx.get_option("ks_mfma_min") == 1 and ckv.ctx.get_option("ks_mfma_min") == 0
     rs = np.random.RandomState(23)
     for B in ((1, 5, 33, 256, 257, 1025, 2100) if which in ("small", "uint2") else (1, 33, 300)):
         trl = rand_u32(rs, (B, 2, k.p.N))
@@ -338,7 +338,7 @@ def test_dispatch_boundaries_gate_shape(oracle, keys_small, ck_small, pkg, B):
 
 
 @pytest.mark.parametrize("which", ["small", "uint1", "uint3"])
-def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which, monkeypatch):
+def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which):
     # kernels_quad.hpp (four waves per bootstrap; eight for L = 3 at <= one bootstrap per CU) against kernels.hpp on the same key and inputs: the
     # accumulators are bit-identical word for word at every prefix of the CMUX chain, for all three N = 1024
     # gadget shapes (L=3/Bg=2^6: exact regime, whole chains; Uint1 L=2/Bg=2^10 and Uint3 L=1/Bg=2^23: tolerance
@@ -349,15 +349,16 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which,
         p = oracle.params(which).small(16)
         bsk_t = rand_u32(np.random.RandomState(5), (p.n, 2 * p.L, 2, p.N))
     ksk = np.zeros((p.N * p.t * (1 << p.basebit), p.n + 1), np.uint32)
-    monkeypatch.setenv("TFHE_QUAD_MAX", "0")
     ck2 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
-    monkeypatch.setenv("TFHE_QUAD_MAX", "1000000")
+    ck2.ctx.set_option("quad_max", 0)
     ck4 = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
+    ck4.ctx.set_option("quad_max", 1000000)
     # ... and with the eight-wave kernel switched off (it serves L = 3 launches of at most one bootstrap per CU)
-    monkeypatch.setenv("TFHE_OCT_MAX", "0")
-    ck4only = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk) if which != "uint3" else None     # L = 1: no eight-wave form
-    monkeypatch.delenv("TFHE_QUAD_MAX")
-    monkeypatch.delenv("TFHE_OCT_MAX")
+    ck4only = None
+    if which != "uint3":                                                   # L = 1: no eight-wave form
+        ck4only = pkg.CloudKey(gpu_params(pkg, p), bsk_torus=bsk_t, ksk=ksk)
+        ck4only.ctx.set_option("quad_max", 1000000)
+        ck4only.ctx.set_option("oct_max", 0)
     rs = np.random.RandomState(21)
     for B in (1, 5, 300):            # 300 > one workgroup per CU: the two-per-CU instance of the four-wave kernel
         cts = rand_u32(rs, (B, p.n + 1))

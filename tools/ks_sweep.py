@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Vector-ALU vs matrix-core key switch (kernels.hpp vs keyswitch_mfma.hpp) on ONE box, interleaved:
    python tools/ks_sweep.py [--sizes 16,64,128,256,512,1024,4096] [--params 128]
-Two contexts on the same random key, one created with TFHE_KS_MFMA_MIN=0 (never), one with TFHE_KS_MFMA_MIN=1
+Two contexts on the same random key, one with option ks_mfma_min = 0 (never), one with ks_mfma_min = 1
 (always); checks the outputs are bit-identical and prints the key-switch time per batch size (HIP events)."""
 import argparse, json, os, sys
 import numpy as np, torch
@@ -21,11 +21,10 @@ rs = np.random.RandomState(3)
 rnd = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
 bsk, ksk = rnd((p.n, 2 * p.L, 2, p.N)), rnd((p.ksk_rows, p.n + 1))
 def make(v):
-    os.environ["TFHE_KS_MFMA_MIN"] = v
     ck = pkg.CloudKey(p, bsk_torus=bsk, ksk=ksk)
-    del os.environ["TFHE_KS_MFMA_MIN"]
+    ck.ctx.set_option("ks_mfma_min", v)
     return ck
-ckv, ckm = make("0"), make("1")
+ckv, ckm = make(0), make(1)
 sizes = [int(x) for x in args.sizes.split(",")]
 trl = torch.from_numpy(rnd((max(sizes), 2, p.N)).view(np.int32)).cuda()
 res = {}

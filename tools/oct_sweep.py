@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Four-wave vs eight-wave blind rotate (kernels_quad.hpp) on ONE box, interleaved:
    python tools/oct_sweep.py [--rounds 4] [--launches 6] [--sizes 1,32,64,128,256]
-Two contexts on the same random 128-bit key, one created with TFHE_OCT_MAX=0 (four waves per bootstrap for
+Two contexts on the same random 128-bit key, one with option oct_max = 0 (four waves per bootstrap for
 launches of at most one bootstrap per CU), one with the default; checks the accumulators are bit-identical (also
 against the two-wave kernel) and prints the blind-rotate kernel time per batch size (HIP events)."""
 import argparse, json, os, sys
@@ -20,13 +20,12 @@ p = pkg.params.BY_NAME["128"]
 rs = np.random.RandomState(3)
 rnd = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
 bsk, ksk = rnd((p.n, 2 * p.L, 2, p.N)), rnd((p.ksk_rows, p.n + 1))
-def make(env):
-    os.environ.update(env)
+def make(opts):
     ck = pkg.CloudKey(p, bsk_torus=bsk, ksk=ksk)
-    for k in env: del os.environ[k]
+    for k, v in opts.items(): ck.ctx.set_option(k, v)
     return ck
-ck2 = make({"TFHE_QUAD_MAX": "0"})
-ck4 = make({"TFHE_OCT_MAX": "0"})
+ck2 = make({"quad_max": 0})
+ck4 = make({"oct_max": 0})
 ck8 = make({})
 sizes = [int(x) for x in args.sizes.split(",")]
 cts = torch.from_numpy(rnd((max(sizes), p.n + 1)).view(np.int32)).cuda()

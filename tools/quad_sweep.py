@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Two-wave vs four-wave blind rotate (kernels.hpp vs kernels_quad.hpp) on ONE box, interleaved:
    python tools/quad_sweep.py [--rounds 4] [--launches 6] [--sizes 1,64,128,256,384,512]
-Two contexts on the same random 128-bit key, one created with TFHE_QUAD_MAX=0 (always two waves per
-bootstrap), one with TFHE_QUAD_MAX=<huge>; checks the two kernels' accumulators are bit-identical and prints
+Two contexts on the same random 128-bit key, one with option quad_max = 0 (always two waves per
+bootstrap), one with quad_max = <huge>; checks the two kernels' accumulators are bit-identical and prints
 the blind-rotate kernel time per batch size (HIP events, tfhe_last_kernel_ms)."""
 import argparse, json, os, sys
 import numpy as np, torch
@@ -22,11 +22,8 @@ p = pkg.params.BY_NAME[args.params]
 rs = np.random.RandomState(3)
 rnd = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
 bsk, ksk = rnd((p.n, 2 * p.L, 2, p.N)), rnd((p.ksk_rows, p.n + 1))
-os.environ["TFHE_QUAD_MAX"] = "0"
-ck2 = pkg.CloudKey(p, bsk_torus=bsk, ksk=ksk)
-os.environ["TFHE_QUAD_MAX"] = str(args.quad_limit)
-ck4 = pkg.CloudKey(p, bsk_torus=bsk, ksk=ksk)
-del os.environ["TFHE_QUAD_MAX"]
+ck2 = pkg.CloudKey(p, bsk_torus=bsk, ksk=ksk); ck2.ctx.set_option("quad_max", 0)
+ck4 = pkg.CloudKey(p, bsk_torus=bsk, ksk=ksk); ck4.ctx.set_option("quad_max", args.quad_limit)
 sizes = [int(x) for x in args.sizes.split(",")]
 Bmax = max(sizes)
 cts = torch.from_numpy(rnd((Bmax, p.n + 1)).view(np.int32)).cuda()
