@@ -357,6 +357,16 @@ class Context:
         self._check(self._lib.tfhe_bootstrap_batch_dev(self._h, _devptr(cts, (B, n1), d, what="cts"), tvp, per,
                                                        _devptr(out, (B, n1), d, what="out"), B, self._stream(stream)))
 
+    def bootstrap_extended_batch_dev(self, cts, lut, out, stream=None):
+        """tfhe_bootstrap_extended_batch_dev: lut = GPU tensor [ext][2][N] (shared) or [B][ext][2][N]."""
+        B, n1, d, N = cts.shape[0], self.params.n + 1, self.device, self.params.N
+        per = 1 if lut.dim() == 4 else 0
+        ext = lut.shape[1] if per else lut.shape[0]
+        shape = (B, ext, 2, N) if per else (ext, 2, N)
+        self._check(self._lib.tfhe_bootstrap_extended_batch_dev(self._h, _devptr(cts, (B, n1), d, what="cts"),
+                                                                _devptr(lut, shape, d, what="lut"), per, int(ext),
+                                                                _devptr(out, (B, n1), d, what="out"), B, self._stream(stream)))
+
     def blind_rotate_batch_dev(self, cts, testvec, out, nsteps=-1, stream=None):
         B, n1, d = cts.shape[0], self.params.n + 1, self.device
         tvp, per = self._tv_dev(testvec, B)

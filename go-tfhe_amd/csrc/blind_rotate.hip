@@ -26,23 +26,19 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         a.first = a0.first + base;
         a.batch = cnt;
         const dim3 g(cnt);
-        if (shape_is_1024(shape) && cnt <= quad_max) {
-            // one workgroup per CU: one wave per SIMD, all key levels prefetched; two per CU: two waves per SIMD
-            if (cnt <= num_cus && cnt <= oct_limit && shape != kShapeN1024_L1_B23) {
-                // one bootstrap per CU on eight waves (two or three gadget levels to split)
+        if (shape_is_1024(shape) && cnt <= quad_max && cnt <= num_cus) {
+            // at most one bootstrap per CU: eight waves per bootstrap where there are two or three gadget levels to split,
+            // four otherwise (one wave per SIMD, all key levels prefetched).  The four-wave kernel at TWO workgroups per CU
+            // (257...512 bootstraps) loses to the paired two-wave form below -- 4.31 vs 4.05 ms at 512, measured again in
+            // round 3 with its twiddle loads scalar (profiles/r03_b_midsize.txt) -- and is no longer instantiated.
+            if (cnt <= oct_limit && shape != kShapeN1024_L1_B23) {
                 if (shape == kShapeN1024_L3_B6) hipLaunchKernelGGL((k_blind_rotate_oct<3, 6>), g, dim3(512), 0, st, a);
                 else hipLaunchKernelGGL((k_blind_rotate_oct<2, 10>), g, dim3(512), 0, st, a);
-            } else if (cnt <= num_cus) {
+            } else {
                 switch (shape) {
                 case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 1>), g, dim3(256), 0, st, a); break;
                 case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate_quad<2, 10, 1, 1>), g, dim3(256), 0, st, a); break;
                 default: hipLaunchKernelGGL((k_blind_rotate_quad<1, 23, 1, 1>), g, dim3(256), 0, st, a); break;
-                }
-            } else {
-                switch (shape) {
-                case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 2>), g, dim3(256), 0, st, a); break;
-                case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate_quad<2, 10, 1, 2>), g, dim3(256), 0, st, a); break;
-                default: hipLaunchKernelGGL((k_blind_rotate_quad<1, 23, 1, 2>), g, dim3(256), 0, st, a); break;
                 }
             }
             continue;
@@ -53,6 +49,9 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         //   257..512  items: TWO per 4-wave workgroup, one per CU: the hardware leaves a SIMD idle with two 2-wave
         //                    workgroups per CU (see k_blind_rotate), 5.15 -> 4.42 ms at 512;
         //   513..768  items: one item per workgroup (pairing measured 6.40 vs 5.65 ms at 768).
+#ifdef BR_FULL_ITEMS2
+        if (shape == kShapeN1024_L3_B6 && cnt > 3 * num_cus) { hipLaunchKernelGGL((k_blind_rotate<3, 6, 2>), dim3((cnt + 1) / 2), dim3(256), 0, st, a); continue; }
+#endif
         if (shape_is_1024(shape) && cnt > 3 * num_cus) {
             const dim3 g4((cnt + 3) / 4);
             switch (shape) {
@@ -84,6 +83,13 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
             break;
         }
     }
+}
+
+void launch_blind_rotate_ext2(const BlindRotateArgs &a0, int B, hipStream_t st)
+{
+    BlindRotateArgs a = a0;
+    a.batch = B;
+    hipLaunchKernelGGL((k_blind_rotate_2048<22, false, 2>), dim3(B), dim3(512), 0, st, a);
 }
 
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,

@@ -309,9 +309,15 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
     clk.mark(4);
+#ifdef BR_ALT
+    // the inverse transform runs in the PARTNER's scratch, whose content (the partner's products for this wave) this
+    // wave has just consumed; the caller alternates the two buffers between steps, so no second barrier is needed
+    fft512_inverse_pipe(keep, const_cast<cd *>(sc_other), table, tw, lane);
+#else
     __syncthreads();
     clk.mark(5);
     fft512_inverse_pipe(keep, sc_mine, table, tw, lane);
+#endif
     // |v| <= 2L * N * (Bg/2) * 2^31: below 2^51 the 1.5*2^52 trick is exact (L=3, Bgbit=6: 2^48.6);
     // the Uint1 / Uint3 shapes (L=2,Bgbit=10: 2^52; L=1,Bgbit=23: 2^64) need the wide form and sit in
     // the tolerance regime, like the reference's own fp64 pipeline at those sets.
@@ -386,7 +392,11 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
         const DiffSource S{accL[p], at, nullptr};
+#ifdef BR_ALT
+        external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, K, sc[p ^ (i & 1)], sc[p ^ 1 ^ (i & 1)], A.tw, tw, A.offset, p, lane, clk);
+#else
         external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane, clk);
+#endif
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
         for (int q = 0; q < 16; q++) lds_add(&accL[p][64 * q + lane], e[q]);

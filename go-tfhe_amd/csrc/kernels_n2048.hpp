@@ -184,12 +184,21 @@ __device__ __forceinline__ void external_product_core_2048(Coef coef /* j -> coe
     }
 }
 
+// Extended lookup tables (see ExtendedArgs below): rotation amount s and source component src for target component k of
+// Y^a * acc, a = ext*q + r: component k comes from component (k - r) mod ext rotated by X^(q + [k < r]).
+__device__ __forceinline__ void ext_rotation(int a, int ext, int k, int &src, int &s)
+{
+    const int q = a / ext, r = a - q * ext;
+    src = k - r; if (src < 0) src += ext;
+    s = q + (k < r ? 1 : 0);
+}
+
 // Blind rotate for N = 2048 with FOUR waves per bootstrap (one workgroup): wave (p, h) owns half h of the root tree
 // (X^512 = +-rho) of accumulator polynomial p.  A batch of 512 PBS puts two workgroups on each CU = two waves on every
 // SIMD (fp64 issue ~5.5 instead of ~8 cycles per instruction).  Per CMUX step and wave, FOUR s_barriers:
 //
 //   extract   the digits of the wave's OWN 16 coefficients of X^a~ * acc - acc (points a in [4h, 4h+4) and a + 8, re and
-//             im): rotated operand from the polynomial's signed table in LDS, own operand from registers; fold them
+//             im): rotated operand from the polynomial's accumulator in LDS, own operand from registers; fold them
 //             to both half-trees (lo +- rho*hi), keep this half-tree's four inputs, hand the other four to the sibling
 //   barrier 1
 //   forward   512-point transform of the half-tree, products with the 8 + 8 key slices: the partner polynomial's
@@ -199,51 +208,77 @@ __device__ __forceinline__ void external_product_core_2048(Coef coef /* j -> coe
 //             -- the partner's products for this wave -- was just read by this wave itself, so nothing has to be
 //             waited for: this removed a barrier); the four results the sibling's points need go to LDS
 //   barrier 3
-//   update    undo the radix-2 level for the own points, acc += round(.) in registers and in the signed table
+//   update    undo the radix-2 level for the own points, acc += round(.) in registers and in the LDS accumulator
 //   barrier 4
 //
 // LDS per bootstrap: four exchange scratches (36 KB: FFT exchanges, product hand-over, and -- in the windows where
-// their owner does not use them -- the digit and half-swap hand-overs), the signed accumulator table T[p][2N] =
-// {acc, ~acc} (32 KB: coefficient j of X^a*acc is T[(j - a) mod 2N], the reference's "negation" being the bitwise
-// complement, buffer_methods.go:152,158 -- two VALU instructions of addressing per coefficient instead of eight),
-// the mod-switched mask (2.5 KB): 70.6 KB, two workgroups per CU.
-// Measured (tools/ab_bench.py, Uint5 x 512, interleaved on one box, profiles/r03_a_uint5_steps.txt): 6.65 ms at the
-// start of round 3 -> 6.50 (own points in registers, half-swap of 4 slots, scalar twiddle loads) -> 6.43 (inverse
-// through the partner's scratch) -> 6.01 (one bootstrap per workgroup again: with four barriers the two workgroups of
-// a CU run better unsynchronised) -> this form.
+// their owner does not use them -- the digit and half-swap hand-overs), the accumulator (16 KB), the mod-switched
+// mask (2.5 KB): 55.8 KB, two workgroups per CU (the registers, 218, allow no third).
+// Measured (tools/ab_bench.py, Uint5 x 512, interleaved on one box; profiles/r03_a_uint5_steps.txt): 6.66 ms at the
+// start of round 3 -> 6.50 (own points in registers, half-swap of 4 slots instead of 8, scalar twiddle loads)
+// -> 6.43 (inverse through the partner's scratch: four barriers) -> 6.02 (one bootstrap per workgroup again: with four
+// barriers two unsynchronised workgroups per CU beat one eight-wave workgroup) -> 5.94 (hand-overs inside the scratches,
+// twiddle powers built once).  Tried and dropped: a signed table {acc, ~acc} for the rotated reads (-100 VALU per
+// step but 16 more LDS stores: 6.18 ms -- the kernel is bound by LDS traffic before it is bound by issue slots); key
+// slices requested at the top of the step at two workgroups per CU (6.85 ms; it is what the <= 256 launches use); a
+// forced half-step offset between the two workgroups of a CU (6.11-6.15 ms).
 // KEYS_FIRST: the step's 16 key slices are requested at its top and held in 64 VGPRs (launches of at most one workgroup
 // per CU, where nothing else covers the L2 latency: 4.76 -> 4.34 ms at 256); with two workgroups per CU they are
 // requested where they are used, under the last level of the forward transform (6.10 vs 6.15 ms at 512).
-template <int BGBIT, bool KEYS_FIRST>
-__global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
+//
+// EXT = 2: the same kernel over an EXTENDED lookup table of 2N entries (polyExtendFactor 2: the Uint6 set, params.go:396-403;
+// the algebra is at ExtendedArgs below).  The table is two ring elements, the workgroup two four-wave groups, group c
+// holding accumulator component c.  Every word is mod-switched to [0, 4N); a step with a = 2q + r updates
+//     acc_c <- acc_c + bsk[i] (x) (X^(q + [c < r]) acc_((c - r) mod 2) - acc_c):
+// the only difference to EXT = 1 is WHICH component's signed table the rotated operand is read from, and by how much.
+// All eight waves share the four barriers, so every rotated read of a step precedes every update of that step.
+// 141 KB of LDS: one bootstrap per CU, two waves per SIMD.  A.tv = lut [2][2][N] (+ tv_stride per item), A.in1 unused.
+template <int BGBIT, bool KEYS_FIRST, int EXT = 1>
+__global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs A)
 {
     constexpr int N = 2048;
     constexpr double r = 0.70710678118654752440;
-    __shared__ cd sc[4][kScratchSlots];
-    __shared__ uint32_t accT[2][2 * N];           // signed table per polynomial: T[s] = acc[s], T[N + s] = ~acc[s]
+    __shared__ cd scAll[EXT][4][kScratchSlots];
+    __shared__ uint32_t accL[EXT][2][N];          // the accumulator polynomials (per component): the operand of the ROTATED reads
     __shared__ uint16_t abarL[kMaxLweDim];
     __shared__ int btL;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int wAll = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int w = wAll & 3, comp = EXT > 1 ? wAll >> 2 : 0;
     const int p = w >> 1, h = w & 1;
+    cd (&sc)[4][kScratchSlots] = scAll[comp];
     const int item = A.first + blockIdx.x;
     if (!gate_item_live(A, item)) return;           // list entries past the device-side count (kernels.hpp)
     const int n = A.n;
-    const bool bad_op = gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
+    bool bad_op = false;
+    if constexpr (EXT == 1) {
+        bad_op = gate_prep_modswitch(A, item, tid, 256, N, abarL, &btL);
+    } else {
+        // round(ct * 2*EXT*N / 2^32) for every word; the body holds 2*EXT*N - that (evaluator.go:116,122 on the big ring)
+        const uint32_t *ct = A.in0 + (size_t)item * (n + 1);
+        constexpr unsigned long long big2 = 2ull * EXT * N;
+        for (int x = tid; x <= n; x += 256 * EXT) {
+            unsigned int a = (unsigned int)(((unsigned long long)ct[x] * big2 + (1ull << 31)) >> 32);
+            if (a >= big2) a -= (unsigned int)big2;
+            if (x == n) btL = (int)((big2 - a) % big2);
+            else abarL[x] = (uint16_t)a;
+        }
+    }
     LaneTwiddles tw;
     const cd *table = A.tw + (size_t)h * kTwCount1024;
     load_lane_twiddles(tw, table, lane);
     __syncthreads();
-    uint32_t *T = accT[p];
+    uint32_t *T = accL[comp][p];
     // Wave h owns the digit points a in [4h, 4h+4) and a + 8 of its polynomial, i.e. coefficients
     // j0 = 256h + 64q + lane (q < 4) and j0 + 1024 (re, im of point a), j0 + 512 and j0 + 1536 (point a + 8): it
     // extracts their digits AND applies their updates, so it keeps them in registers next to the table.
     uint32_t own[4][4];
     auto own_j = [&](int q, int k) { return 256 * h + 64 * q + lane + 512 * (k >> 1) + 1024 * (k & 1); };
     {
-        // acc = X^b~ * testvec (evaluator.go:116-118, buffer_methods.go:133-164)
-        const int bt = btL & (2 * N - 1);
-        const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + (size_t)p * N;
+        // acc = X^b~ * testvec (evaluator.go:116-118, buffer_methods.go:133-164); EXT > 1: component comp of Y^b~ * LUT
+        int bt = btL & (2 * N - 1), src = 0;
+        if constexpr (EXT > 1) ext_rotation(btL, EXT, comp, src, bt);
+        const uint32_t *tv = A.tv + (size_t)item * A.tv_stride + ((size_t)src * 2 + p) * N;
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -253,7 +288,6 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
                 v ^= 0u - (uint32_t)((s >> 11) & 1);      // "negation" is the bitwise complement
                 own[q][k] = v;
                 T[j] = v;
-                T[j + N] = ~v;
             }
     }
     __syncthreads();
@@ -276,7 +310,13 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
     PhaseClock clk;
     clk.start();
     for (int i = 0; i < A.nsteps; i++) {
-        const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        const uint32_t *Trot = T;                       // table the rotated operand is read from
+        if constexpr (EXT > 1) {
+            int src;
+            ext_rotation(at, EXT, comp, src, at);
+            Trot = accL[src][p];
+        }
         const cd *kp = key + (size_t)i * kStep;
         const cd *kKeep = kp + (size_t)(p ? 1 : 0) * 1024;
         const cd *kSend = kp + (size_t)(p ? 0 : 1) * 1024;
@@ -292,7 +332,8 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
             int dg[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {            // k = 0: re of point a, 1: im of a, 2: re of a + 8, 3: im of a + 8
-                const uint32_t v = T[(own_j(q, k) - at) & (2 * N - 1)];
+                const int sx = (own_j(q, k) - at) & (2 * N - 1);
+                const uint32_t v = Trot[sx & (N - 1)] ^ (0u - (uint32_t)((sx >> 11) & 1));     // "negation" = complement
                 const uint32_t d = v - own[q][k] + A.offset;         // X^at*acc - acc (evaluator.go:93-96), + offset
                 dg[k] = (int)((d >> shift) & mask) - half;           // decomposer.go:60-65
             }
@@ -352,7 +393,6 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
             for (int k = 0; k < 4; k++) {
                 own[q][k] += round_to_torus_wide(z[k]);                    // acc += e (evaluator.go:102-105)
                 T[own_j(q, k)] = own[q][k];
-                T[own_j(q, k) + N] = ~own[q][k];
             }
         }
         clk.mark(8);
@@ -363,11 +403,13 @@ __global__ __launch_bounds__(256) void k_blind_rotate_2048(BlindRotateArgs A)
     clk.store(A.out + (size_t)item * 2 * N, w, lane);
     return;
 #endif
-    uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
+    if (comp == 0) {                                    // sample extraction reads coefficient 0 of component 0 only
+        uint32_t *out = A.out + (size_t)item * 2 * N + (size_t)p * N;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
+        for (int q = 0; q < 4; q++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) out[own_j(q, k)] = own[q][k];
+            for (int k = 0; k < 4; k++) out[own_j(q, k)] = own[q][k];
+    }
     report_bad_op(A, bad_op, tid);
 }
 
@@ -413,13 +455,6 @@ struct ExtendedArgs {
     uint32_t offset;
 };
 
-// rotation amount and source component for target component k of Y^a * acc
-__device__ __forceinline__ void ext_rotation(int a, int ext, int k, int &src, int &s)
-{
-    const int q = a / ext, r = a - q * ext;
-    src = k - r; if (src < 0) src += ext;
-    s = q + (k < r ? 1 : 0);
-}
 __device__ __forceinline__ uint32_t rot_coeff_2048(const uint32_t *__restrict__ poly, int s, int j)
 {
     const int t = (j - s) & 4095;                       // X^s * poly, X^2048 = -1; "negation" is the complement

@@ -21,6 +21,9 @@ inline bool shape_is_512(int shape) { return shape == kShapeN512_L1_B18; }
 // quad_limit: N = 1024 launches of up to this many items use the four-wave kernel (kernels_quad.hpp);
 // oct_limit: of those, launches of up to this many (and at most one per CU) use the eight-wave kernel.
 void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, int num_cus, int quad_limit, int oct_limit, hipStream_t st);
+// Persistent blind rotate through an extended lookup table with polyExtendFactor 2 (kernels_n2048.hpp, EXT = 2): one
+// eight-wave workgroup per item; args.tv = lut [2][2][N] (tv_stride 0 or 4N), args.in1 / ops / idx unused.
+void launch_blind_rotate_ext2(const BlindRotateArgs &args, int B, hipStream_t st);
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
                              uint32_t offset, int B, hipStream_t st);
 } // namespace tfhe

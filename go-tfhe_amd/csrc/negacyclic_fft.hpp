@@ -79,12 +79,7 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 // k_blind_rotate_quad x128: 3.19 -> 3.10 ms.  The burst forms and the other rejected variants (unpadded scratch,
 // spread hand-over stores, static priorities) are recorded in profiles/ and no longer compiled.
 constexpr int kPipeValu = 10;       // batched forward transforms: VALU instructions per DS instruction (5 / 8 / 10: 6.15 / 6.13 / 6.11 ms)
-#ifdef PIPE1V
-constexpr int kPipe1Valu = PIPE1V;
-#else
-constexpr int kPipe1Valu = 3;
-#endif
-//       // single transforms (N = 2048 blind rotate): VALU instructions between two stores
+constexpr int kPipe1Valu = 3;       // single transforms (N = 2048 blind rotate): VALU instructions between two stores
 
 __device__ __forceinline__ void wave_lds_order()
 {
@@ -164,6 +159,16 @@ __device__ __forceinline__ TwAll expand_pow_once(const TwPow &t)
 {
     TwAll a;
     a.w3 = cmul(t.w1, t.w2); a.w5 = cmul(t.w1, t.w4); a.w6 = cmul(t.w2, t.w4);
+    a.w7 = cmul(a.w3, t.w4);
+    return a;
+}
+// The rebuild kept inside a loop by a NON-volatile asm whose extra input changes with the loop (dep): see above.
+__device__ __forceinline__ TwAll expand_pow(const TwPow &t, int dep)
+{
+    cd w1 = t.w1;
+    asm("" : "+v"(w1.re), "+v"(w1.im) : "s"(dep));
+    TwAll a;
+    a.w3 = cmul(w1, t.w2); a.w5 = cmul(w1, t.w4); a.w6 = cmul(t.w2, t.w4);
     a.w7 = cmul(a.w3, t.w4);
     return a;
 }

@@ -580,36 +580,71 @@ int bootstrap_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, in
     return TFHE_OK;
 }
 
-// Programmable bootstrap through an extended lookup table (kernels_n2048.hpp: ExtendedArgs), N = 2048 shape only.
+// Programmable bootstrap through an extended lookup table (kernels_n2048.hpp), N = 2048 shape only.
+//   ext = 2 (Uint6): the persistent eight-wave kernel -- both accumulator components in LDS, all n steps in one launch;
+//   other ext:       one launch per CMUX step over (item, component) pairs, accumulators double-buffered in global memory
+//                    (a functional path for the experimental sets), in chunks of items so that the buffers have a
+//                    fixed size whatever the batch.
 int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_lut, int lut_per_item, int ext,
                               uint32_t *d_out, int B, hipStream_t st)
 {
     if (c->shape != kShapeN2048_L1_B22) return fail(TFHE_E_INVALID, "extended lookup tables need the N = 2048 parameter shape");
     if (ext < 1 || ext > 16) return fail(TFHE_E_INVALID, "polyExtendFactor %d out of range (1..16)", ext);
     const size_t N = 2048, n1 = (size_t)c->P.n + 1;
-    const size_t accw = (size_t)ext * B * 2 * N;
     int rc;
-    if ((rc = grow(c, c->s_t2, 2 * accw * sizeof(uint32_t), st, "extended accumulator")) ||
-        (rc = grow(c, c->s_t3, (size_t)B * n1 * sizeof(uint32_t), st, "mod-switched sample"))) return rc;
-    uint32_t *acc[2] = {c->s_t2.as<uint32_t>(), c->s_t2.as<uint32_t>() + accw};
-    ExtendedArgs a{};
-    a.bsk = c->bsk.as<cd>(); a.tw = c->tw.as<cd>();
-    a.in = d_in; a.lut = d_lut; a.lut_stride = lut_per_item ? (long)ext * 2 * N : 0;
-    a.amod = c->s_t3.as<uint32_t>();
-    a.n = c->P.n; a.ext = ext; a.B = B; a.offset = c->offset;
-    a.acc_out = acc[0];
-    hipEvent_t stop;
-    int trc = timing_begin(c, 0, st, &stop);
-    if (trc) return trc;
-    hipLaunchKernelGGL(k_ext_init_2048, dim3(B), dim3(256), 0, st, a);
-    for (int i = 0; i < c->P.n; i++) {
-        a.step = i; a.acc_in = acc[i & 1]; a.acc_out = acc[(i + 1) & 1];
-        hipLaunchKernelGGL((k_cmux_ext_2048<22>), dim3((unsigned)(B * ext)), dim3(128), 0, st, a);
+    if (ext == 2) {
+        const int slab = slab_items(c);
+        if ((rc = reserve_scratch(c, B, false, st))) return rc;
+        for (int base = 0; base < B; base += slab) {
+            const int S = B - base < slab ? B - base : slab;
+            BlindRotateArgs a{};
+            a.bsk = c->bsk.as<cd>(); a.tw = c->tw.as<cd>();
+            a.in0 = d_in + (size_t)base * n1;
+            a.tv = d_lut + (lut_per_item ? (size_t)base * ext * 2 * N : 0);
+            a.tv_stride = lut_per_item ? (long)ext * 2 * N : 0;
+            a.out = c->s_trlwe.as<uint32_t>();
+            a.n = c->P.n; a.nsteps = c->P.n; a.Nbit = c->P.Nbit; a.offset = c->offset;
+            a.op_uniform = -1;
+            a.status = c->status.as<int>();
+            hipEvent_t stop;
+            if ((rc = timing_begin(c, 0, st, &stop))) return rc;
+            launch_blind_rotate_ext2(a, S, st);
+            HIP_TRY(hipGetLastError());
+            if ((rc = timing_end(c, 0, st, stop))) return rc;
+            if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), d_out + (size_t)base * n1, S, nullptr, st))) return rc;
+        }
+        return TFHE_OK;
     }
-    HIP_TRY(hipGetLastError());
-    if ((rc = timing_end(c, 0, st, stop))) return rc;
-    // component 0 of the final accumulators is contiguous [B][2][N]: sample extract + key switch as usual
-    return launch_keyswitch(c, acc[c->P.n & 1], d_out, B, nullptr, st);
+    const int chunk = launch_items(c);                       // items per pass: the accumulators are 2 * ext * chunk TRLWE samples
+    const int Bc = B < chunk ? B : chunk;
+    const size_t accw = (size_t)ext * Bc * 2 * N;
+    if ((rc = grow(c, c->s_t2, 2 * accw * sizeof(uint32_t), st, "extended accumulator")) ||
+        (rc = grow(c, c->s_t3, (size_t)Bc * n1 * sizeof(uint32_t), st, "mod-switched sample"))) return rc;
+    uint32_t *acc[2] = {c->s_t2.as<uint32_t>(), c->s_t2.as<uint32_t>() + accw};
+    for (int base = 0; base < B; base += chunk) {
+        const int S = B - base < chunk ? B - base : chunk;
+        ExtendedArgs a{};
+        a.bsk = c->bsk.as<cd>(); a.tw = c->tw.as<cd>();
+        a.in = d_in + (size_t)base * n1;
+        a.lut = d_lut + (lut_per_item ? (size_t)base * ext * 2 * N : 0);
+        a.lut_stride = lut_per_item ? (long)ext * 2 * N : 0;
+        a.amod = c->s_t3.as<uint32_t>();
+        a.n = c->P.n; a.ext = ext; a.B = S; a.offset = c->offset;
+        a.acc_out = acc[0];
+        hipEvent_t stop;
+        int trc = timing_begin(c, 0, st, &stop);
+        if (trc) return trc;
+        hipLaunchKernelGGL(k_ext_init_2048, dim3(S), dim3(256), 0, st, a);
+        for (int i = 0; i < c->P.n; i++) {
+            a.step = i; a.acc_in = acc[i & 1]; a.acc_out = acc[(i + 1) & 1];
+            hipLaunchKernelGGL((k_cmux_ext_2048<22>), dim3((unsigned)((size_t)S * ext)), dim3(128), 0, st, a);
+        }
+        HIP_TRY(hipGetLastError());
+        if ((rc = timing_end(c, 0, st, stop))) return rc;
+        // component 0 of the final accumulators is contiguous [S][2][N]: sample extract + key switch as usual
+        if ((rc = launch_keyswitch(c, acc[c->P.n & 1], d_out + (size_t)base * n1, S, nullptr, st))) return rc;
+    }
+    return TFHE_OK;
 }
 
 // Host-pointer gate batch longer than one piece (pipe_items: 16,384 bootstraps at N = 1024): the operands of piece s+1
@@ -1251,9 +1286,9 @@ int tfhe_bootstrap_extended_batch(tfhe_ctx *c, const uint32_t *in, const uint32_
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!in || !lut || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (ext < 1 || ext > 16) return fail(TFHE_E_INVALID, "polyExtendFactor %d out of range (1..16)", ext);
-    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
     std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     const size_t inb = (size_t)B * (c->P.n + 1) * 4, lutb = (size_t)(lut_per_item ? B : 1) * ext * 2 * c->P.N * 4;
     if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_out.reserve(inb)) || (rc = c->s_tv.reserve(lutb))) return rc;
     HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));

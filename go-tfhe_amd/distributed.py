@@ -11,6 +11,10 @@ import time
 
 import numpy as np
 
+from ._binding import OPS
+
+OP_NAMES = {v: k for k, v in OPS.items()}
+
 
 def shard_bounds(total, world, rank):
     """Contiguous range [lo, hi) of rank's shard: [g*B/G, (g+1)*B/G)."""
@@ -21,14 +25,37 @@ def shard_sizes(total, world):
     return [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
 
 
-def broadcast_cloud_key(ctx, src=0, group=None):
+def _bcast_header(dist, words, root, group, device):
+    """The few integers every rank needs before a scatter (batch size, plane count, uniform op code ...) as ONE fixed
+    4-word int32 tensor broadcast on the backend's own device -- not broadcast_object_list, which pickles, moves the
+    bytes through two collectives and synchronises the host on every call."""
+    import torch
+    h = torch.zeros(4, dtype=torch.int32, device=device)
+    if words is not None:
+        h[: len(words)] = torch.tensor(list(words), dtype=torch.int32)
+    dist.broadcast(h, src=root, group=group)
+    return [int(x) for x in h.tolist()]
+
+
+def broadcast_cloud_key(ctx, src=0, group=None, via_host=False):
     """Replicate the cloud key loaded (or generated) in rank `src`'s context into every other rank's context:
     one broadcast per key of the engine's device-layout blob (tfhe_key_export_dev / tfhe_key_import_dev; 68.8 MB +
-    77.9 MB at 128-bit) over xGMI, instead of every rank uploading or regenerating it."""
+    77.9 MB at 128-bit) over xGMI, instead of every rank uploading or regenerating it.  The receiving
+    library checks each blob's header (parameter set, key kind, layout version, length) before installing it.
+    via_host: stage the blobs through host memory (backends that move CPU tensors: the gloo dry runs and CPU tests)."""
     import torch.distributed as dist
     rank = dist.get_rank(group)
     import torch
     for which in (0, 1):
+        if via_host:
+            if rank == src:
+                blob = torch.from_numpy(ctx.key_export(which))
+            else:
+                blob = torch.empty(ctx.key_size(which), dtype=torch.uint8)
+            dist.broadcast(blob, src=src, group=group)
+            if rank != src:
+                ctx.key_import(which, blob.numpy())
+            continue
         if rank == src:
             blob = ctx.key_export_dev(which, torch.cuda.current_stream())
         else:
@@ -36,7 +63,8 @@ def broadcast_cloud_key(ctx, src=0, group=None):
         dist.broadcast(blob, src=src, group=group)
         if rank != src:
             ctx.key_import_dev(which, blob, torch.cuda.current_stream())
-    torch.cuda.current_stream().synchronize()
+    if not via_host:
+        torch.cuda.current_stream().synchronize()
 
 
 class ShardedGates:
@@ -89,7 +117,7 @@ class ShardedGates:
             for r in range(W):
                 lo, hi = shard_bounds(total, W, r)
                 buf[r, planes * cap * n1: planes * cap * n1 + (hi - lo)] = o32[lo:hi]
-        return buf, [total, planes, None if per_item else ops]
+        return buf, [total, planes, -1 if per_item else OPS[ops]]
 
     def gate_batch(self, ops, a, b, c=None, total=None, root=0, packed=None):
         """ops: str (uniform) or uint8 tensor [B] on root; a, b, c: int32/uint32-bit tensors [B][n+1]
@@ -100,9 +128,9 @@ class ShardedGates:
         if self.rank == root:
             buf, meta = packed if packed is not None else self.pack(ops, a, b, c)
         else:
-            buf, meta = None, [None] * 3
-        dist.broadcast_object_list(meta, src=root, group=self.group)
-        total, planes, uniform = meta
+            buf, meta = None, None
+        total, planes, ucode, _ = _bcast_header(dist, meta, root, self.group, self.device)
+        uniform = None if ucode < 0 else OP_NAMES[ucode]
         sizes = shard_sizes(total, W)
         cap = max(max(sizes), 1)
         mine_n = sizes[self.rank]
@@ -150,40 +178,50 @@ class ShardedCircuits:
 
     def run(self, in_wires, out_wires, inputs=None, root=0):
         """inputs (root): int32 tensor [len(in_wires)][C][n+1]; returns (root) [len(out_wires)][C][n+1].
-        C must be a multiple of the world size."""
+        Any C: rank r owns the contiguous circuits shard_bounds(C, world, r) (shares differ by at most one; the
+        scatter and gather buffers are padded to the largest share, a rank without circuits computes nothing)."""
         import torch
         dist, W, n1 = self.dist, self.world, self.n1
         t0 = time.perf_counter()
-        meta = [inputs.shape[1] if self.rank == root else None]
-        dist.broadcast_object_list(meta, src=root, group=self.group)
-        C = meta[0]
-        if C % W:
-            raise ValueError("the number of circuits must be a multiple of the world size")
-        Cl, I = C // W, len(in_wires)
-        mine = torch.empty((I, Cl, n1), dtype=torch.int32, device=self.device)
+        C = _bcast_header(dist, [inputs.shape[1]] if self.rank == root else None, root, self.group, self.device)[0]
+        sizes = shard_sizes(C, W)
+        cap, I = max(max(sizes), 1), len(in_wires)
+        mine_n = sizes[self.rank]
+        mine = torch.empty((I, cap, n1), dtype=torch.int32, device=self.device)
         chunks = None
-        if self.rank == root:                                 # [I][W][Cl][n1] -> [W][I][Cl][n1], one copy
-            chunks = list(inputs.view(I, W, Cl, n1).permute(1, 0, 2, 3).contiguous().unbind(0))
+        if self.rank == root:
+            if C == cap * W:                                  # [I][W][cap][n1] -> [W][I][cap][n1], one copy
+                chunks = list(inputs.view(I, W, cap, n1).permute(1, 0, 2, 3).contiguous().unbind(0))
+            else:
+                pad = torch.zeros((W, I, cap, n1), dtype=torch.int32, device=self.device)
+                for r in range(W):
+                    lo, hi = shard_bounds(C, W, r)
+                    pad[r, :, : hi - lo] = inputs[:, lo:hi]
+                chunks = list(pad.unbind(0))
         dist.scatter(mine, chunks, src=root, group=self.group)
         self._sync()
         t1 = time.perf_counter()
-        wires = torch.zeros((self.n_wires, Cl, n1), dtype=torch.int32, device=self.device)
-        wires[torch.tensor(list(in_wires), device=self.device)] = mine
-        ret = self.run_local(wires)              # in place, or returns the finished wire tensor
-        if ret is not None:
-            wires = ret
-        res = wires[torch.tensor(list(out_wires), device=self.device)].contiguous()
+        O = len(out_wires)
+        res = torch.zeros((O, cap, n1), dtype=torch.int32, device=self.device)
+        if mine_n:
+            wires = torch.zeros((self.n_wires, mine_n, n1), dtype=torch.int32, device=self.device)
+            wires[torch.tensor(list(in_wires), device=self.device)] = mine[:, :mine_n]
+            ret = self.run_local(wires)              # in place, or returns the finished wire tensor
+            if ret is not None:
+                wires = ret
+            res[:, :mine_n] = wires[torch.tensor(list(out_wires), device=self.device)]
         self._sync()
         t2 = time.perf_counter()
-        O = len(out_wires)
-        gathered = torch.empty((W, O, Cl, n1), dtype=torch.int32, device=self.device) if self.rank == root else None
+        gathered = torch.empty((W, O, cap, n1), dtype=torch.int32, device=self.device) if self.rank == root else None
         dist.gather(res, list(gathered.unbind(0)) if self.rank == root else None, dst=root, group=self.group)
         self._sync()
         t3 = time.perf_counter()
         self.last_timing = {"scatter_s": t1 - t0, "compute_s": t2 - t1, "gather_s": t3 - t2}
         if self.rank != root:
             return None
-        return gathered.permute(1, 0, 2, 3).reshape(O, C, n1)
+        if C == cap * W:
+            return gathered.permute(1, 0, 2, 3).reshape(O, C, n1)
+        return torch.cat([gathered[r, :, : sizes[r]] for r in range(W)], dim=1)
 
 
 def gpu_compute(ctx):

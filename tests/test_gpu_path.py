@@ -360,7 +360,7 @@ def test_four_wave_kernel_equals_two_wave_kernel(pkg, oracle, keys_small, which)
         ck4only.ctx.set_option("quad_max", 1000000)
         ck4only.ctx.set_option("oct_max", 0)
     rs = np.random.RandomState(21)
-    for B in (1, 5, 300):            # 300 > one workgroup per CU: the two-per-CU instance of the four-wave kernel
+    for B in (1, 5, 300):            # 300 > one workgroup per CU: past the small-batch kernels, both contexts take the paired two-wave form
         cts = rand_u32(rs, (B, p.n + 1))
         cts[0] = 0
         tvs = rand_u32(rs, (B, 2, p.N))

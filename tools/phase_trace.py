@@ -33,7 +33,7 @@ oct_kernel = not n2048 and B <= torch.cuda.get_device_properties(0).multi_proces
 W = 4 if n2048 else 4 * args.groups if oct_kernel else 2
 NM = 10 if n2048 else 9 if oct_kernel else 8
 t = o.cpu().numpy().view(np.int64).reshape(B, -1)[:, :16 * W].reshape(B, W, 16)[:, :, :NM] / p.n
-names = (["extract", "barrier1", "fwd+mac", "barrier2", "gather", "barrier3", "inv+store", "barrier4", "update", "barrier5"] if n2048 else
+names = (["extract", "barrier1", "fwd+mac", "barrier2", "gather", "(unused)", "inv+send", "barrier3", "update", "barrier4"] if n2048 else
          ["keys+dec", "forward", "mac+store", "barrier1", "gather", "inv+store", "barrier2", "update", "barrier3"] if oct_kernel else
          ["decompose", "forward", "mac+keys", "barrier1", "gather", "barrier2", "inverse", "update"])
 print("kernel ms", ck.ctx.last_kernel_ms(0), "N=2048 four-wave" if n2048 else f"{4 * args.groups}-wave" if oct_kernel else "two-wave")
