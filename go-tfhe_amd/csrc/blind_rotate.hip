@@ -49,9 +49,6 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         //   257..512  items: TWO per 4-wave workgroup, one per CU: the hardware leaves a SIMD idle with two 2-wave
         //                    workgroups per CU (see k_blind_rotate), 5.15 -> 4.42 ms at 512;
         //   513..768  items: one item per workgroup (pairing measured 6.40 vs 5.65 ms at 768).
-#ifdef BR_FULL_ITEMS2
-        if (shape == kShapeN1024_L3_B6 && cnt > 3 * num_cus) { hipLaunchKernelGGL((k_blind_rotate<3, 6, 2>), dim3((cnt + 1) / 2), dim3(256), 0, st, a); continue; }
-#endif
         if (shape_is_1024(shape) && cnt > 3 * num_cus) {
             const dim3 g4((cnt + 3) / 4);
             switch (shape) {

@@ -242,7 +242,7 @@ __device__ __forceinline__ uint32_t diff_coeff(const DiffSource &S, int j)
 // them with its L key rows into partial sums for BOTH outputs, hands the partner's partial sum
 // over through LDS, and inverse-transforms its own.
 // (evaluator.go:50-81; decomposer.go:55-66; fourier_ops.go:167-191)
-template <int L, int BGBIT>
+template <int L, int BGBIT, bool ALT = false>
 __device__ __forceinline__ void external_product_core(const DiffSource &S, uint32_t (&e)[16],
                                                       const cd *__restrict__ key_ip, /* &bsk[i][p] */
                                                       KeyRegs &K, /* scratch: the level's key slices */
@@ -309,15 +309,18 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
     clk.mark(4);
-#ifdef BR_ALT
-    // the inverse transform runs in the PARTNER's scratch, whose content (the partner's products for this wave) this
-    // wave has just consumed; the caller alternates the two buffers between steps, so no second barrier is needed
-    fft512_inverse_pipe(keep, const_cast<cd *>(sc_other), table, tw, lane);
-#else
-    __syncthreads();
-    clk.mark(5);
-    fft512_inverse_pipe(keep, sc_mine, table, tw, lane);
-#endif
+    if constexpr (ALT) {
+        // ONE barrier per step: the inverse transform runs in the PARTNER's scratch, whose content (the partner's products
+        // for this wave) this very wave has just consumed, and the caller swaps the two buffers' roles every step -- a
+        // buffer is then only ever touched by the wave that used it last, until the next barrier hands it over.
+        // 5.93 -> 5.84 ms at 1,024 bootstraps (four per workgroup), nothing at 512, +3 % at 768 (one per workgroup):
+        // used by the four-per-workgroup launch shape only (profiles/r03_d_headline_variants.txt).
+        fft512_inverse_pipe(keep, const_cast<cd *>(sc_other), table, tw, lane);
+    } else {
+        __syncthreads();
+        clk.mark(5);
+        fft512_inverse_pipe(keep, sc_mine, table, tw, lane);
+    }
     // |v| <= 2L * N * (Bg/2) * 2^31: below 2^51 the 1.5*2^52 trick is exact (L=3, Bgbit=6: 2^48.6);
     // the Uint1 / Uint3 shapes (L=2,Bgbit=10: 2^52; L=1,Bgbit=23: 2^64) need the wide form and sit in
     // the tolerance regime, like the reference's own fp64 pipeline at those sets.
@@ -392,11 +395,9 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
         const DiffSource S{accL[p], at, nullptr};
-#ifdef BR_ALT
-        external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, K, sc[p ^ (i & 1)], sc[p ^ 1 ^ (i & 1)], A.tw, tw, A.offset, p, lane, clk);
-#else
-        external_product_core<L, BGBIT>(S, e, key + (size_t)i * kStep, K, sc[p], sc[p ^ 1], A.tw, tw, A.offset, p, lane, clk);
-#endif
+        constexpr bool kAlt = ITEMS == 4;                 // see external_product_core
+        const int mine = kAlt ? p ^ (i & 1) : p;
+        external_product_core<L, BGBIT, kAlt>(S, e, key + (size_t)i * kStep, K, sc[mine], sc[mine ^ 1], A.tw, tw, A.offset, p, lane, clk);
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
         for (int q = 0; q < 16; q++) lds_add(&accL[p][64 * q + lane], e[q]);
