@@ -562,11 +562,18 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
                 sc[k * 64 + lane] = keep[k];
                 sendG[0][ph][k * 64 + lane] = send[k];
             }
+            wave_lds_order();       // (*) see below
         } else {
             oct_forward<L, BGBIT, L0, L1>(A, Tp, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
 #pragma unroll
             for (int k = 0; k < 4; k++) sendG[1][ph][k * 64 + lane] = send[k];
+            wave_lds_order();       // (*)
         }
+        // (*) Every conditional block of this loop ENDS IN A FENCE (no instruction: wavefront scope).  LLVM marks a uniform
+        // global load "not clobbered" -- the precondition for s_load -- by walking MemorySSA upwards; at a control-flow
+        // merge it tests each incoming definition WITHOUT alias analysis, so a block ending in a plain LDS store makes
+        // every wave-uniform twiddle load of the loop a global_load + s_waitcnt vmcnt (eight per step here, four of them
+        // on the serial tail).  Fences are skipped by that test, and the walk behind them is alias-aware again.
         tr.mark(2);
         __syncthreads();
         tr.mark(3);
@@ -578,6 +585,7 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
             fft256_inverse(keep, sc, T, tw, q);
 #pragma unroll
             for (int k = 0; k < 4; k++) swapAll[ph][k * 64 + lane] = keep[k];
+            wave_lds_order();       // (*)
             tr.mark(5);
         }
         __syncthreads();
