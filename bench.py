@@ -176,7 +176,7 @@ def measured_ceilings():
 
 
 # VALU instructions a wave of k_blind_rotate<3,6,4> issues per CMUX step (SQ_INSTS_VALU / waves / steps of the committed
-# rocprofv3 PMC pass, profiles/r03_e_pmc_summary.txt: 2.215e9 / 2048 / 700) and its occupancy: what `roofline.attainable`
+# rocprofv3 PMC pass, profiles/r03_f_pmc_summary.txt: 2.215e9 / 2048 / 700) and its occupancy: what `roofline.attainable`
 # is computed from
 BR_VALU_PER_WAVE_STEP = 1545
 BR_WAVES_PER_SIMD = 2
