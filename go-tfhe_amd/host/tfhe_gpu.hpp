@@ -121,6 +121,20 @@ class CloudKey {
         check(tfhe_keygen_cloud_seeded(ck->ctx_, keyLv0.data(), keyLv1.data(), alphaLv0, alphaLv1, seed128));
         return ck;
     }
+    // The engine's serialised form of the two keys (the reference has none): which = 0 bootstrapping key, 1 key-switching
+    // key; a blob carries a header (parameter set, key kind, device-layout version, length) that Import checks -- a blob
+    // of another set / kind / library build, or a truncated one, is a Panic and installs nothing (include/tfhe_hip.h).
+    std::vector<uint8_t> Export(int which) const
+    {
+        size_t bytes = 0;
+        check(tfhe_key_size(ctx_, which, &bytes));
+        std::vector<uint8_t> blob(bytes);
+        check(tfhe_key_export(ctx_, which, blob.data()));
+        return blob;
+    }
+    void Import(int which, const std::vector<uint8_t> &blob) { check(tfhe_key_import(ctx_, which, blob.data(), blob.size())); }
+    // an empty context of the given parameters, to Import a cloud key into
+    static std::unique_ptr<CloudKey> Empty(const params::Params &p, int device = 0) { return std::make_unique<CloudKey>(p, nullptr, nullptr, device); }
     ~CloudKey() { if (ctx_) tfhe_ctx_destroy(ctx_); }
     CloudKey(const CloudKey &) = delete;
     CloudKey &operator=(const CloudKey &) = delete;

@@ -150,6 +150,23 @@ int main()
         bool threw6 = false;
         try { g6.GenLookUpTable([](int x) { return x; }); } catch (const Panic &) { threw6 = true; }
         EXPECT(threw6, "an extended generator must refuse to build an N-coefficient table");
+        // the cloud key through its serialised form into a second context: identical ciphertexts; a blob of the wrong kind,
+        // a truncated one and one offered to another parameter set are refused
+        auto ck5b = cloudkey::CloudKey::Empty(p5);
+        const auto blob0 = ck5->Export(0), blob1 = ck5->Export(1);
+        ck5b->Import(0, blob0);
+        ck5b->Import(1, blob1);
+        evaluator::Evaluator ev5b(*ck5b);
+        gates::Ciphertext ct(o5.n);
+        orc_tlwe_encrypt_message(&o5, &rng, 17, 64, k0.data(), ct.P.data());
+        EXPECT(ev5.BootstrapLUTExtended(ct, t6).P == ev5b.BootstrapLUTExtended(ct, t6).P, "imported key computes different ciphertexts");
+        int refused = 0;
+        try { ck5b->Import(0, blob1); } catch (const Panic &e) { refused += e.code == TFHE_E_INVALID; }
+        try { ck5b->Import(1, std::vector<uint8_t>(blob1.begin(), blob1.end() - 4)); } catch (const Panic &e) { refused += e.code == TFHE_E_INVALID; }
+        params::Params p5c = p5;
+        p5c.n = 25;
+        try { cloudkey::CloudKey::Empty(p5c)->Import(0, blob0); } catch (const Panic &e) { refused += e.code == TFHE_E_INVALID; }
+        EXPECT(refused == 3, "mismatched key blobs must be refused (%d of 3 were)", refused);
     }
     // error behaviour: a Go panic is a thrown Panic
     bool threw = false;

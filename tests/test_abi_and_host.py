@@ -91,7 +91,8 @@ def test_schedule_min_cost_is_valid_and_no_worse():
     import __graft_entry__ as graft
     graft.load_package()
     from go_tfhe_amd.circuits import ripple_carry_adder, balance_levels, schedule_min_cost, launch_cost_ms
-    assert [launch_cost_ms(b) for b in (1, 256, 257, 1024, 1025)] == [2.75, 2.75, 4.17, 6.04, 6.04 + 2.75]
+    c = launch_cost_ms                                   # a step function of the launch shape (measured values: profiles/r03_*)
+    assert c(1) == c(256) < c(257) == c(512) < c(513) == c(768) < c(769) == c(1024) and abs(c(1025) - (c(1024) + c(1))) < 1e-9
     for bits, fold, inst in ((8, False, 256), (8, True, 256), (4, False, 32), (16, True, 100)):
         levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=fold)
         got = schedule_min_cost(levels, inst)
