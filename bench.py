@@ -180,6 +180,9 @@ def measured_ceilings():
 # is computed from
 BR_VALU_PER_WAVE_STEP = 1545
 BR_WAVES_PER_SIMD = 2
+# ... and its DS instructions per wave and step: 4 transforms x 2 exchanges x 8 + 8 (product hand-over) 16-byte stores and as many
+# loads, 32 accumulator reads, 16 accumulator adds (192; SQ_INSTS_LDS / waves / steps = 186: a few accumulator reads pair up)
+BR_DS_PER_WAVE_STEP = {"ds_write_b128": 72, "ds_read_b128": 72, "ds_read_b32": 32, "ds_add_u32": 16}
 
 
 class KernelTimer:
@@ -548,6 +551,18 @@ def main():
                     f"fp64 Tflop/s if the kernel's {BR_VALU_PER_WAVE_STEP} VALU instructions per wave and CMUX step issued at the rate "
                     f"tools/ubench_ceilings measured on this box for {BR_WAVES_PER_SIMD} resident waves per SIMD ({ns:.3f} ns per instruction per SIMD; "
                     "the nominal peak assumes one every 4 cycles and 2 flop per lane, an FFT's mix is 1.42)")
+                # the kernel's other pipe: DS instructions per wave and CMUX step (by kind; from the source and SQ_INSTS_LDS of the
+                # committed PMC pass) x their measured cost on this box x the eight resident waves of a CU, over the step's time
+                ld = ceil["lds_ns_per_wave_instr_per_cu"]
+                per_wave_ns = (BR_DS_PER_WAVE_STEP["ds_write_b128"] * ld["ds_write_b128"] + BR_DS_PER_WAVE_STEP["ds_read_b128"] * ld["ds_read_b128"]
+                               + BR_DS_PER_WAVE_STEP["ds_read_b32"] * ld["ds_read_b32"] + BR_DS_PER_WAVE_STEP["ds_add_u32"] * ld["ds_add_u32"])
+                step_ns = br_avg_ms * 1e6 / p.n
+                line["roofline"]["lds_pipe"] = {
+                    "ds_instructions_per_wave_step": BR_DS_PER_WAVE_STEP, "measured_ns_per_wave_instruction_per_cu": ld,
+                    "busy_frac": 4 * BR_WAVES_PER_SIMD * per_wave_ns / step_ns,
+                    "store_share": BR_DS_PER_WAVE_STEP["ds_write_b128"] * ld["ds_write_b128"] / per_wave_ns,
+                    "note": "fraction of a CMUX step the CU's LDS pipe is busy with the kernel's DS instructions at their measured throughput "
+                            "(8 waves per CU); the store path (ds_write_b128) is the narrow one -- DESIGN.md section 3"}
                 line["roofline"]["hbm_streaming"]["measured_copy_GBps"] = ceil["hbm_copy"]["kernel_copy_GBps"]
                 line["roofline"]["hbm_streaming"]["x_measured_copy"] = stream_gbs / ceil["hbm_copy"]["kernel_copy_GBps"]
             except Exception:

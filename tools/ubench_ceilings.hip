@@ -2,6 +2,8 @@
 //   * fp64 vector issue rate per SIMD at 1 / 2 / 4 resident waves per SIMD (independent v_fma_f64 / v_add_f64 chains,
 //     ILP 8): the blind-rotate kernels hold 2 waves per SIMD (256 VGPRs), and a SIMD with two waves does not reach
 //     the 4-cycle cadence the nominal 78.6 Tflop/s assumes -- this is what "attainable at the kernel's occupancy" means;
+//   * LDS instruction throughput per CU for the four DS instruction kinds of the blind-rotate kernels (the store path is the
+//     narrow one: a ds_write_b128 costs ~14 cycles of CU time, a ds_read_b128 ~4);
 //   * device-to-device copy bandwidth (a plain 16 B/lane copy kernel and hipMemcpyDtoD over 1 GiB): the HBM rate this
 //     box actually delivers, next to the nominal 8 TB/s.
 // Prints ONE JSON object.  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_ceilings.hip -o tools/ubench_ceilings.bin
@@ -22,6 +24,33 @@ template <int OP, int ILP> __global__ void k_dp(double *out, int iters, double s
     double s = 0;
     for (int i = 0; i < ILP; i++) s += x[i];
     out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// LDS instruction throughput per CU (tools/ubench_ldsrate.hip has the full table): bursts of 32 conflict-free DS instructions of
+// one kind per wave, 8 waves per CU.  KIND 0 ds_read_b32, 1 ds_read_b128, 2 ds_write_b128, 3 ds_add_u32.
+template <int KIND> __global__ __launch_bounds__(256) void k_lds(uint32_t *out, int iters)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ uint4 buf[4096];                       // 64 KB: two workgroups per CU
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += 256) buf[i] = make_uint4(i, 1, 2, 3);
+    __syncthreads();
+    const uint32_t base = (uint32_t)(size_t)&buf[w * 1024];
+    const uint32_t a32 = base + lane * 4, a128 = base + lane * 16;
+    uint32_t r0 = 0, acc = 0;
+    u32x4 r2 = {0, 0, 0, 0};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            if (KIND == 0) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r0) : "v"(a32), "n"((c & 15) * 256));
+            if (KIND == 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r2) : "v"(a128), "n"((c & 15) * 1024));
+            if (KIND == 2) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(a128), "v"(r2), "n"((c & 15) * 1024));
+            if (KIND == 3) asm volatile("ds_add_u32 %0, %1 offset:%2" ::"v"(a32), "v"(acc), "n"((c & 15) * 256));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        acc += r0 + r2.x;
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
 __global__ void k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
@@ -65,6 +94,19 @@ int main()
                    op == 0 ? "add" : "fma", wps, ns_per_inst, lane_ops_per_s / 1e12, lane_ops_per_s * (op == 0 ? 1 : 2) / 1e12);
             first = false;
         }
+    }
+    printf("}, \"lds_ns_per_wave_instr_per_cu\": {");
+    {
+        uint32_t *lout; CHECK(hipMalloc(&lout, (size_t)cus * 2 * 256 * 4));
+        const int it2 = 2000;
+        const double ops_per_cu = 2.0 * 4 * it2 * 32;          // two workgroups of four waves per CU
+        float t0 = best_ms([&] { hipLaunchKernelGGL(k_lds<0>, dim3(cus * 2), dim3(256), 0, 0, lout, it2); }, 3);
+        float t1 = best_ms([&] { hipLaunchKernelGGL(k_lds<1>, dim3(cus * 2), dim3(256), 0, 0, lout, it2); }, 3);
+        float t2 = best_ms([&] { hipLaunchKernelGGL(k_lds<2>, dim3(cus * 2), dim3(256), 0, 0, lout, it2); }, 3);
+        float t3 = best_ms([&] { hipLaunchKernelGGL(k_lds<3>, dim3(cus * 2), dim3(256), 0, 0, lout, it2); }, 3);
+        printf("\"ds_read_b32\": %.4f, \"ds_read_b128\": %.4f, \"ds_write_b128\": %.4f, \"ds_add_u32\": %.4f", t0 * 1e6 / ops_per_cu,
+               t1 * 1e6 / ops_per_cu, t2 * 1e6 / ops_per_cu, t3 * 1e6 / ops_per_cu);
+        (void)hipFree(lout);
     }
     printf("}, ");
     const size_t bytes = (size_t)1 << 30;
