@@ -73,6 +73,36 @@ def test_extended_lut_full_message_space(oracle, pkg, name, ext, modulus, n):
     ck.close()
 
 
+def test_extended_lut_persistent_kernel_large_batch_and_device_path(oracle, pkg):
+    # polyExtendFactor 2 runs the persistent eight-wave kernel (one workgroup of 141 KB LDS per item): a batch larger than
+    # the CU count (workgroups queue), per-item tables at that size, and the enqueue-only device entry point -- all
+    # decrypt-level, and the device path word for word equal to the host-pointer path
+    import torch
+    from go_tfhe_amd.lut import Generator
+    ks = KeySet(oracle, "uint5", 0x7F4E0057, n_override=20, torus=False)
+    ck = _ctx(pkg, ks)
+    modulus, ext, B = 64, 2, 300
+    gen = Generator(ks.p, modulus, polyExtendFactor=ext)
+    rs = np.random.RandomState(58)
+    msgs = rs.randint(0, modulus, B)
+    cts = _encrypt(oracle, ks, msgs, modulus)
+    f = lambda x: (3 * x + 5) % modulus
+    lut = gen.GenLookUpTableExtended(f)
+    out = ck.ctx.bootstrap_extended_batch(cts, lut)
+    assert np.array_equal(_decrypt(oracle, ks, out, modulus), np.array([f(int(m)) for m in msgs]))
+    shifts = rs.randint(0, 4, B)
+    tables = np.stack([gen.GenLookUpTableExtended(lambda x, s=s: (x + s) % modulus) for s in range(4)])
+    out2 = ck.ctx.bootstrap_extended_batch(cts, tables[shifts])
+    assert np.array_equal(_decrypt(oracle, ks, out2, modulus), (msgs + shifts) % modulus)
+    d_cts = torch.from_numpy(cts.view(np.int32)).cuda()
+    d_lut = torch.from_numpy(lut.view(np.int32)).cuda()
+    d_out = torch.zeros_like(d_cts)
+    ck.ctx.bootstrap_extended_batch_dev(d_cts, d_lut, d_out)
+    ck.ctx.sync()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint32), out)
+    ck.close()
+
+
 def test_extended_lut_matches_oracle_composition(oracle, pkg):
     from go_tfhe_amd.lut import Generator
     ks = KeySet(oracle, "uint5", 0x7F4E0055, n_override=12, torus=False)

@@ -490,3 +490,32 @@ def test_concurrent_host_threads(oracle, keys_small, ck_small, pkg):
     for i in range(len(jobs)):
         assert np.array_equal(got[i], want[i]), i
     ck2.close()
+
+
+def test_options_are_per_context_and_validated(pkg, keys_small):
+    # tfhe_ctx_set_option / tfhe_ctx_get_option (include/tfhe_hip.h): defaults, round trip, negative = default, unknown
+    # option refused; nothing comes from the environment (a stray TFHE_* variable must not change dispatch)
+    import os
+    os.environ["TFHE_QUAD_MAX"] = "0"
+    os.environ["TFHE_KS_MFMA_MIN"] = "0"
+    try:
+        ck = pkg.CloudKey(gpu_params(pkg, keys_small.p), bsk_fourier=keys_small.bsk, ksk=keys_small.ksk)
+    finally:
+        del os.environ["TFHE_QUAD_MAX"], os.environ["TFHE_KS_MFMA_MIN"]
+    ctx = ck.ctx
+    cus = ctx.get_option("quad_max")
+    assert cus > 0 and ctx.get_option("oct_max") == cus and ctx.get_option("ks_mfma_min") == 1 and ctx.get_option("frozen") == 0
+    ctx.set_option("quad_max", 7); ctx.set_option("oct_max", 3); ctx.set_option("ks_mfma_min", 100)
+    assert (ctx.get_option("quad_max"), ctx.get_option("oct_max"), ctx.get_option("ks_mfma_min")) == (7, 3, 100)
+    for name in ("quad_max", "oct_max", "ks_mfma_min"):
+        ctx.set_option(name, -1)
+    assert (ctx.get_option("quad_max"), ctx.get_option("oct_max"), ctx.get_option("ks_mfma_min")) == (cus, cus, 1)
+    with pytest.raises(pkg.TfheError, match="unknown option"):
+        ctx._check(ctx._lib.tfhe_ctx_set_option(ctx._h, 99, 1))
+    # the same gates under every dispatch setting: identical ciphertexts
+    a, b = keys_small.enc([0, 1, 1, 0] * 4), keys_small.enc([1, 1, 0, 0] * 4)
+    want = ctx.gate_batch("XOR", a, b)
+    for q, o, m in ((0, 0, 0), (1000000, 0, 1), (1000000, 1000000, 0)):
+        ctx.set_option("quad_max", q); ctx.set_option("oct_max", o); ctx.set_option("ks_mfma_min", m)
+        assert np.array_equal(ctx.gate_batch("XOR", a, b), want), (q, o, m)
+    ck.close()
