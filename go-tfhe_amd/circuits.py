@@ -115,7 +115,7 @@ def launch_cost_ms(bootstraps, full=1024):
     kernel, up to 512 the two-wave kernel with two bootstraps per four-wave workgroup, then the two-wave kernel at three
     (one per workgroup) and four (four per eight-wave workgroup) bootstraps per CU; longer levels are full launches
     plus a tail."""
-    steps = ((256, 2.57), (512, 4.14), (768, 5.42), (1024, 5.97))
+    steps = ((256, 2.57), (512, 4.04), (768, 5.42), (1024, 5.97))
     n_full, rem = divmod(int(bootstraps), full)
     t = n_full * steps[-1][1]
     if rem:

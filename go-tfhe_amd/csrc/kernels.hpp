@@ -255,15 +255,14 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     // multiplied into the two accumulators level by level.
     cd x[L][8];
     {
-        constexpr uint32_t mask = (1u << BGBIT) - 1u;
-        constexpr int half = 1 << (BGBIT - 1);
 #pragma unroll
         for (int a = 0; a < 8; a++) {
-            const uint32_t d0 = diff_coeff(S, 64 * a + lane) + offset, d1 = diff_coeff(S, 64 * a + lane + 512) + offset;
+            constexpr uint32_t flip = digit_flip_mask<L, BGBIT>();
+            const uint32_t d0 = (diff_coeff(S, 64 * a + lane) + offset) ^ flip, d1 = (diff_coeff(S, 64 * a + lane + 512) + offset) ^ flip;
 #pragma unroll
             for (int l = 0; l < L; l++) {
                 const int shift = 32 - (l + 1) * BGBIT;
-                x[l][a] = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
+                x[l][a] = cd{(double)digit_of<BGBIT>(d0, shift), (double)digit_of<BGBIT>(d1, shift)};
             }
         }
     }

@@ -326,8 +326,6 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
     const cd *key = A.bskq + ((size_t)p * 2 + h) * (L * 2 * 256);
     const int partner = w ^ 2, sibling = w ^ 1;
     const double sr = h ? -r : r;                                // (-1)^h / sqrt2
-    constexpr uint32_t mask = (1u << BGBIT) - 1u;
-    constexpr int half = 1 << (BGBIT - 1);
     constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;      // see external_product_core
     const int nsteps = A.nsteps;
     for (int i = 0; i < nsteps; i++) {
@@ -350,13 +348,13 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
                 const int s = (j - at) & (2 * N - 1);
                 uint32_t v = acc[s & (N - 1)];
                 v ^= 0u - (uint32_t)((s >> 10) & 1);
-                dd[k] = v - acc[j] + A.offset;
+                dd[k] = (v - acc[j] + A.offset) ^ digit_flip_mask<L, BGBIT>();
             }
 #pragma unroll
             for (int l = 0; l < L; l++) {
                 const int shift = 32 - (l + 1) * BGBIT;
-                const int lo_re = (int)((dd[0] >> shift) & mask) - half, hi_re = (int)((dd[1] >> shift) & mask) - half;
-                const int lo_im = (int)((dd[2] >> shift) & mask) - half, hi_im = (int)((dd[3] >> shift) & mask) - half;
+                const int lo_re = digit_of<BGBIT>(dd[0], shift), hi_re = digit_of<BGBIT>(dd[1], shift);
+                const int lo_im = digit_of<BGBIT>(dd[2], shift), hi_im = digit_of<BGBIT>(dd[3], shift);
                 x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
             }
         }
@@ -448,8 +446,6 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
                                             cd (&send)[4], PhaseClock &tr)
 {
     constexpr int N = 1024;
-    constexpr uint32_t mask = (1u << BGBIT) - 1u;
-    constexpr int half = 1 << (BGBIT - 1);
     QuadKeys K[NL];
 #pragma unroll
     for (int l = 0; l < NL; l++) load_quad_keys(K[l], key_iph + (size_t)(LB + l) * 512, p, lane);
@@ -461,12 +457,12 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
     for (int a = 0; a < 4; a++) {
         uint32_t dd[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) dd[k] = rot[64 * a + 256 * k] - own[64 * a + 256 * k] + A.offset;
+        for (int k = 0; k < 4; k++) dd[k] = (rot[64 * a + 256 * k] - own[64 * a + 256 * k] + A.offset) ^ digit_flip_mask<L, BGBIT>();
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             const int shift = 32 - (LB + l + 1) * BGBIT;
-            const int lo_re = (int)((dd[0] >> shift) & mask) - half, hi_re = (int)((dd[1] >> shift) & mask) - half;
-            const int lo_im = (int)((dd[2] >> shift) & mask) - half, hi_im = (int)((dd[3] >> shift) & mask) - half;
+            const int lo_re = digit_of<BGBIT>(dd[0], shift), hi_re = digit_of<BGBIT>(dd[1], shift);
+            const int lo_im = digit_of<BGBIT>(dd[2], shift), hi_im = digit_of<BGBIT>(dd[3], shift);
             x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
         }
     }

@@ -492,6 +492,21 @@ __device__ __forceinline__ void fft512_inverse_pipe(cd (&x)[8], cd *sc, const cd
     for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
 }
 
+// Gadget digits without the subtraction (decomposer.go:60-65: digit_l = ((tmp >> shift_l) & (Bg-1)) - Bg/2).  Flipping the top
+// bit of a Bgbit-wide field and reading the field as a two's-complement number IS that subtraction, so with
+// tmpx = tmp ^ digit_flip_mask (one XOR per coefficient, all levels at once) every digit is ONE v_bfe_i32:
+// -1 VALU instruction per digit, exact on integers (bit-identical outputs).
+template <int L, int BGBIT> __host__ __device__ constexpr uint32_t digit_flip_mask()
+{
+    uint32_t m = 0;
+    for (int l = 0; l < L; l++) m |= 1u << (32 - (l + 1) * BGBIT + BGBIT - 1);
+    return m;
+}
+template <int BGBIT> __device__ __forceinline__ int digit_of(uint32_t tmpx, int shift)
+{
+    return __builtin_amdgcn_sbfe((int)tmpx, shift, BGBIT);
+}
+
 // Nearest integer of v, reduced mod 2^32.  Replaces floatModQInPlace + the uint32(int64())
 // conversion of the reference (fourier_transform.go:88-125).  Adding 1.5*2^52 leaves the
 // rounded integer in the low mantissa bits (two's complement), valid for |v| < 2^51; the
