@@ -176,9 +176,9 @@ def measured_ceilings():
 
 
 # VALU instructions a wave of k_blind_rotate<3,6,4> issues per CMUX step (SQ_INSTS_VALU / waves / steps of the committed
-# rocprofv3 PMC pass, profiles/r03_f_pmc_summary.txt: 2.215e9 / 2048 / 700) and its occupancy: what `roofline.attainable`
+# rocprofv3 PMC pass, profiles/r03_i_pmc_summary.txt: 2.1465e9 / 2048 / 700) and its occupancy: what `roofline.attainable`
 # is computed from
-BR_VALU_PER_WAVE_STEP = 1545
+BR_VALU_PER_WAVE_STEP = 1497
 BR_WAVES_PER_SIMD = 2
 # ... and its DS instructions per wave and step: 4 transforms x 2 exchanges x 8 + 8 (product hand-over) 16-byte stores and as many
 # loads, 32 accumulator reads, 16 accumulator adds (192; SQ_INSTS_LDS / waves / steps = 186: a few accumulator reads pair up)
