@@ -392,7 +392,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl" and not share:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            try:                                                 # eager communicator creation: a broken RCCL set-up fails HERE, on every rank
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            except Exception as e:                               # keep the run alive over gloo: the data path has no collective anyway
+                print(f"[bench] rank {rank}: RCCL initialisation failed ({type(e).__name__}: {e}); falling back to gloo "
+                      "(key distribution and the timing reduce then go through host memory)", file=sys.stderr)
+                backend = "gloo"
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:                                                    # two ranks on one GPU cannot form an RCCL communicator
             backend = "gloo"
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
@@ -509,7 +515,7 @@ def main():
             "dtype": "f64", "data": "synthetic (real encryptions of random bits under a seeded cloud key; no external dataset)", "verified": verified,
             "config": {"workload": "BASELINE configs[1]: batch of 1024 independent NAND bootstraps per GPU, "
                                    "128-bit params (n=700, N=1024, L=3, Bgbit=6, t=9), keys+inputs resident in HBM",
-                       "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)",
+                       "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)", "collective_backend": backend if dist else None,
                        "inputs": "real encryptions of random bits under a seeded key (harness PRNG)"},
             "roofline": {"kernel": "k_blind_rotate", "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
