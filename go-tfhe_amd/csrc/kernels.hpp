@@ -692,10 +692,10 @@ __global__ __launch_bounds__(64) void k_keyswitch_pair(KeySwitchArgs A, int B, i
 // to a zero row; each of the 4 waves walks its own 64 ciphertexts: lane = column, the ciphertext's
 // digit is wave-uniform (v_readlane of a per-lane digit word), so the read is one conflict-free
 // ds_read_b32 at a scalar-selected row.  Every key row slice crosses L2 once per 256 ciphertexts.
-// grid = ceil(B/256) * ceil((n+1)/64) * N/IC workgroups (1-D, N/IC a multiple of 8); partial sums are
+// grid = ceil(B/256) * ceil((n+1)/64) * ranges workgroups (1-D, rounded up to the 8 XCDs); partial sums are
 // combined by atomics into the output k_ks_init prepared.  (keyswitch.go:10-37, trlwe_ops.go:10-21)
 template <int BB>
-__global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, int IC, int ct_tiles, int col_blocks)
+__global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, int ranges, int ct_tiles, int col_blocks)
 {
     constexpr int base = 1 << BB, C = 64, CQ = C / 4;            // one column per lane (two per lane: 256 VGPRs,
                                                                  // one wave per SIMD, 0.82 vs 0.61 ms at Uint5 x 512)
@@ -714,8 +714,12 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
         const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
         tile_x = slot % ct_tiles; tile_cr = (slot / ct_tiles) * 8 + xcd;
     }
-    const int b0 = tile_x * 256 + w * 64, c0 = (tile_cr % col_blocks) * C, i0 = (tile_cr / col_blocks) * IC;
-    if (tile_x * 256 >= B) return;                    // whole workgroup (the barriers below are workgroup-wide)
+    // coefficient range cr of `ranges` (any number, not only a divisor of N: the launcher sizes the grid to fill whole rounds of
+    // resident workgroups -- Uint5 x 512: 1,088 workgroups on 768 slots took two rounds, 748 take one)
+    if (tile_x * 256 >= B || tile_cr >= col_blocks * ranges) return;      // whole workgroup (the barriers below are workgroup-wide)
+    const int cr = tile_cr / col_blocks;
+    const int i0 = (int)((long long)cr * N / ranges), IC = (int)((long long)(cr + 1) * N / ranges) - i0;
+    const int b0 = tile_x * 256 + w * 64, c0 = (tile_cr % col_blocks) * C;
     const uint32_t prec = 1u << (32 - (1 + BB * t));
     const int wshift = 32 - BB * t;
     if (tid < C) rowbuf[0][0][tid] = rowbuf[1][0][tid] = 0u;

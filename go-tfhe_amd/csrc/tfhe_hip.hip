@@ -437,17 +437,30 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     // larger bases (Uint sets), batches that fill at least one wave of ciphertexts: column-sliced tiles
     if (c->P.basebit >= 4 && c->P.basebit <= 7 && B >= 64) {
         const int ct_tiles = (B + 255) / 256, col_blocks = (c->P.n + 1 + 63) / 64;
-        int ranges = 8;                                   // coefficient ranges: a multiple of 8 (XCD decode), enough workgroups for 4 per CU
-        while (ranges * 8 < c->P.N && ct_tiles * col_blocks * ranges < 4 * c->num_cus) ranges *= 2;
-        const int IC = c->P.N / ranges;
+        // coefficient ranges: as many as fill k whole rounds of the resident workgroups (three per CU by registers, two at
+        // base 128 by LDS) -- the kernel's time goes with rounds x coefficients per workgroup, so a grid that ends in a
+        // part-filled round wastes the difference (Uint5 x 512: 1,088 workgroups on 768 slots 0.60 ms, 3,060 on 4 x 768
+        // 0.50 ms; profiles/r03_k_keyswitch_rounds.txt).  k = 1...8 with at least 20 coefficients per workgroup: the best
+        // fill, the larger k on a tie (shorter workgroups even out the tail).
+        const int slots = (c->P.basebit >= 7 ? 2 : 3) * c->num_cus, units = ct_tiles * col_blocks;
+        int ranges = 1;
+        double best_fill = 0.0;
+        for (int k = 1; k <= 8; k++) {
+            int r = (int)((long long)k * slots / units);
+            if (r > c->P.N / 20) r = c->P.N / 20;
+            if (r < 1) r = 1;
+            const long long wgs = (long long)units * r, rounds = (wgs + slots - 1) / slots;
+            const double fill = (double)wgs / (double)(rounds * slots);
+            if (fill >= best_fill - 0.005) { if (fill > best_fill) best_fill = fill; ranges = r; }
+        }
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
-        const dim3 g((unsigned)(ct_tiles * col_blocks * ranges));
+        const dim3 g((unsigned)((col_blocks * ranges + 7) / 8 * 8 * ct_tiles));                // XCD decode: see the kernel
         switch (c->P.basebit) {
-        case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
-        case 5: hipLaunchKernelGGL((k_keyswitch_wide<5>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
-        case 6: hipLaunchKernelGGL((k_keyswitch_wide<6>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
-        default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, IC, ct_tiles, col_blocks); break;
+        case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
+        case 5: hipLaunchKernelGGL((k_keyswitch_wide<5>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
+        case 6: hipLaunchKernelGGL((k_keyswitch_wide<6>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
+        default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
         }
         HIP_TRY(hipGetLastError());
         return timing_end(c, 1, st, stop);
