@@ -174,6 +174,34 @@ def test_pbs_full_uint5_batch512(oracle, pkg, keys_u5_full, ck_u5_full):
     assert oracle.decrypt_message(k.p, 32, k.s0, ref) == 5
 
 
+def test_nibble_adder_like_the_reference_example(oracle, pkg, keys_u5_full, ck_u5_full):
+    # examples/add_two_numbers/main.go:37-175, for 64 byte pairs at once: nibbles encrypted mod 32, low nibbles added on the
+    # ciphertexts (no bootstrap), ONE launch extracts sum mod 16 and carry from the same input through per-item lookup
+    # tables, high nibbles + carry added, a second launch extracts the high sum.  Three bootstraps per addition as in the
+    # example; every 8-bit sum must decrypt to (a + b) mod 256 (the example's own check, main.go:160-175)
+    k = keys_u5_full
+    rs = np.random.RandomState(41)
+    a = rs.randint(0, 256, 64); b = rs.randint(0, 256, 64)
+    a[0], b[0] = 42, 137                                             # the example's operands
+    a[1], b[1] = 255, 255
+    a[2], b[2] = 0, 0
+    enc = lambda vals: np.stack([oracle.encrypt_message(k.p, k.rng, int(v), 32, k.s0) for v in vals])
+    a_lo, a_hi, b_lo, b_hi = enc(a & 15), enc(a >> 4), enc(b & 15), enc(b >> 4)
+    lut_sum = oracle.lut_generate(k.p, [x % 16 for x in range(32)])
+    lut_carry = oracle.lut_generate(k.p, [1 if x >= 16 else 0 for x in range(32)])
+    t_lo = a_lo + b_lo                                               # uint32 wrap = torus addition (main.go:103-107)
+    both = ck_u5_full.ctx.bootstrap_batch(np.concatenate([t_lo, t_lo]),
+                                          np.stack([lut_sum] * 64 + [lut_carry] * 64))
+    s_lo, carry = both[:64], both[64:]
+    t_hi = a_hi + b_hi + carry                                       # main.go:125-129
+    s_hi = ck_u5_full.ctx.bootstrap_batch(t_hi, lut_sum)
+    dec = lambda cts: np.array([oracle.decrypt_message(k.p, 32, k.s0, np.ascontiguousarray(c)) for c in cts])
+    lo, hi, cy = dec(s_lo), dec(s_hi), dec(carry)
+    assert np.array_equal(cy, ((a & 15) + (b & 15)) >> 4)
+    assert np.array_equal(lo + 16 * hi, (a + b) % 256)
+    assert (lo[0] + 16 * hi[0]) == 179
+
+
 @pytest.mark.parametrize("name,modulus", [("uint1", 2), ("uint2", 4), ("uint3", 8), ("uint4", 16)])
 def test_pbs_other_uint_sets(oracle, pkg, name, modulus):
     # The other Uint sets the reference tests (params/uint_params_test.go:24-27): Uint1 (N=1024, L=2,
