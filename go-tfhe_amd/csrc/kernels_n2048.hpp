@@ -14,6 +14,7 @@
 // fp64's 53-bit mantissa: like the reference at this parameter set, results are NOT exact
 // integers; the rounding uses the wide form.
 #pragma once
+#include <type_traits>
 
 #include "kernels.hpp"
 
@@ -218,7 +219,9 @@ __device__ __forceinline__ void ext_rotation(int a, int ext, int k, int &src, in
 // start of round 3 -> 6.50 (own points in registers, half-swap of 4 slots instead of 8, scalar twiddle loads)
 // -> 6.43 (inverse through the partner's scratch: four barriers) -> 6.02 (one bootstrap per workgroup again: with four
 // barriers two unsynchronised workgroups per CU beat one eight-wave workgroup) -> 5.94 (hand-overs inside the scratches,
-// twiddle powers built once).  Tried and dropped: a signed table {acc, ~acc} for the rotated reads (-100 VALU per
+// twiddle powers built once) -> 5.85 (the step loop instantiated once per half-tree h: the two h-dependent hand-over
+// patterns are static, 32 v_cndmask per step and a block boundary gone; 5.96 -> 5.85 interleaved on a later, slower
+// box -- FMA contraction moves again, i.e. the bits change inside the tolerance regime).  Tried and dropped: a signed table {acc, ~acc} for the rotated reads (-100 VALU per
 // step but 16 more LDS stores: 6.18 ms -- the kernel is bound by LDS traffic before it is bound by issue slots); key
 // slices requested at the top of the step at two workgroups per CU (6.85 ms; it is what the <= 256 launches use); a
 // forced half-step offset between the two workgroups of a CU (6.11-6.15 ms).
@@ -309,6 +312,9 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
     const TwStep ts{expand_pow_once(tw.l2), expand_pow_once(tw.l3)};
     PhaseClock clk;
     clk.start();
+    auto steps = [&](auto half_tag) {
+    constexpr int H = decltype(half_tag)::value;        // = h, as a constant: the two hand-over patterns below are
+                                                        // static per instance instead of 32 v_cndmask per step
     for (int i = 0; i < A.nsteps; i++) {
         int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         const uint32_t *Trot = T;                       // table the rotated operand is read from
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
         __syncthreads();
         clk.mark(1);
         cd y[8];
-        if (h == 0) {
+        if constexpr (H == 0) {
 #pragma unroll
             for (int q = 0; q < 4; q++) { y[q] = keep[q]; y[4 + q] = drecv[q * 64 + lane]; }
         } else {
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
         // a = 4h + q: it sends the sibling's four values and receives its own four -- half the traffic of exchanging
         // all eight, and both waves do the same work
         cd mine[4];                         // (uniform branches, not selects: those end up in scratch memory)
-        if (h == 0) {
+        if constexpr (H == 0) {
 #pragma unroll
             for (int q = 0; q < 4; q++) { ssend[q * 64 + lane] = y[4 + q]; mine[q] = y[q]; }
         } else {
@@ -399,6 +405,9 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
         __syncthreads();
         clk.mark(9);
     }
+    };
+    if (h == 0) steps(std::integral_constant<int, 0>{});
+    else steps(std::integral_constant<int, 1>{});
 #ifdef PHASE_TRACE
     clk.store(A.out + (size_t)item * 2 * N, w, lane);
     return;
