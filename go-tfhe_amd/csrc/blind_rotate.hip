@@ -43,18 +43,19 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
             }
             continue;
         }
-        // Several items per workgroup (they share only the barriers), measured A/B on one box:
-        //   769..1024 items: FOUR per 8-wave workgroup = every resident wave of a CU in one workgroup, in step on
-        //                    the key stream: 6.84 (one item) -> 6.66 (two) -> 6.38 ms (four) at 1024;
-        //   257..512  items: TWO per 4-wave workgroup, one per CU: the hardware leaves a SIMD idle with two 2-wave
+        // Two items per four-wave workgroup (they share only the barriers), measured A/B on one box:
+        //   769..1024 items: two workgroups on every CU, free-running, with the one-barrier step and the phase priorities
+        //                    (FULL): 5.45 ms at 1,024 against 5.93 for FOUR items in one eight-wave workgroup in step on
+        //                    the key stream (rounds 1-3), 6.27 for the same two workgroups without priorities;
+        //   257..512  items: one such workgroup per CU: the hardware leaves a SIMD idle with two 2-wave
         //                    workgroups per CU (see k_blind_rotate), 5.15 -> 4.42 ms at 512;
         //   513..768  items: one item per workgroup (pairing measured 6.40 vs 5.65 ms at 768).
         if (shape_is_1024(shape) && cnt > 3 * num_cus) {
-            const dim3 g4((cnt + 3) / 4);
+            const dim3 g2((cnt + 1) / 2);
             switch (shape) {
-            case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6, 4>), g4, dim3(512), 0, st, a); break;
-            case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10, 4>), g4, dim3(512), 0, st, a); break;
-            default: hipLaunchKernelGGL((k_blind_rotate<1, 23, 4>), g4, dim3(512), 0, st, a); break;
+            case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6, 2, true>), g2, dim3(256), 0, st, a); break;
+            case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10, 2, true>), g2, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_blind_rotate<1, 23, 2, true>), g2, dim3(256), 0, st, a); break;
             }
             continue;
         }

@@ -242,7 +242,13 @@ __device__ __forceinline__ uint32_t diff_coeff(const DiffSource &S, int j)
 // them with its L key rows into partial sums for BOTH outputs, hands the partner's partial sum
 // over through LDS, and inverse-transforms its own.
 // (evaluator.go:50-81; decomposer.go:55-66; fourier_ops.go:167-191)
-template <int L, int BGBIT, bool ALT = false>
+// PRIO: issue priorities by phase (s_setprio) for the launch shape with two FREE-RUNNING workgroups per CU, where the two
+// waves of a SIMD belong to different workgroups and drift through different phases: decomposition 3, forward
+// transforms 2, products + hand-over 0, gather + inverse transform 1, rounding + accumulator update 3.  The arbiter then
+// favours the wave that is in its LDS-exchange-heavy transforms over the one issuing plain fp64 products, and the
+// workgroups stay out of step instead of queueing at the LDS pipe together.  What matters is forward > inverse >
+// products (equal priorities for the two transforms: 6.27 ms; products = inverse: 5.81; profiles/r03_n_phase_priorities.txt).
+template <int L, int BGBIT, bool ALT = false, bool PRIO = false>
 __device__ __forceinline__ void external_product_core(const DiffSource &S, uint32_t (&e)[16],
                                                       const cd *__restrict__ key_ip, /* &bsk[i][p] */
                                                       KeyRegs &K, /* scratch: the level's key slices */
@@ -253,6 +259,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     cd keep[8], send[8];
     // All L digit polynomials are transformed as one batch (fft512_forward_batch), then
     // multiplied into the two accumulators level by level.
+    if constexpr (PRIO) TFHE_PRIO(3);
     cd x[L][8];
     {
 #pragma unroll
@@ -267,6 +274,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         }
     }
     clk.mark(0);
+    if constexpr (PRIO) TFHE_PRIO(2);
     // level-0 key slices are requested here, under the last level of the forward transforms (~260 fp64
     // instructions), instead of a whole step ahead: 64 VGPRs free during the inverse transform and levels 1-2
     if constexpr (L > 1) fft512_forward_batch_pipe<L>(x, sc_mine, table, tw, lane, [&] {
@@ -276,6 +284,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     });
     else { load_keys(K, key_ip, p, lane); fft512_forward_batch<L>(x, sc_mine, table, tw, lane); }
     clk.mark(1);
+    if constexpr (PRIO) TFHE_PRIO(0);
 #pragma unroll
     for (int l = 0; l < L; l++) {
 #pragma unroll
@@ -305,6 +314,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     clk.mark(2);
     __syncthreads();
     clk.mark(3);
+    if constexpr (PRIO) TFHE_PRIO(1);
 #pragma unroll
     for (int k = 0; k < 8; k++) keep[k] = keep[k] + sc_other[k * 64 + lane];
     clk.mark(4);
@@ -312,8 +322,8 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
         // ONE barrier per step: the inverse transform runs in the PARTNER's scratch, whose content (the partner's products
         // for this wave) this very wave has just consumed, and the caller swaps the two buffers' roles every step -- a
         // buffer is then only ever touched by the wave that used it last, until the next barrier hands it over.
-        // 5.93 -> 5.84 ms at 1,024 bootstraps (four per workgroup), nothing at 512, +3 % at 768 (one per workgroup):
-        // used by the four-per-workgroup launch shape only (profiles/r03_d_headline_variants.txt).
+        // 5.93 -> 5.84 ms at 1,024 bootstraps (then four per workgroup), nothing at 512, +3 % at 768 (one per workgroup):
+        // used by the full-launch shape only (profiles/r03_d_headline_variants.txt).
         fft512_inverse_pipe(keep, const_cast<cd *>(sc_other), table, tw, lane);
     } else {
         __syncthreads();
@@ -323,6 +333,7 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
     // |v| <= 2L * N * (Bg/2) * 2^31: below 2^51 the 1.5*2^52 trick is exact (L=3, Bgbit=6: 2^48.6);
     // the Uint1 / Uint3 shapes (L=2,Bgbit=10: 2^52; L=1,Bgbit=23: 2^64) need the wide form and sit in
     // the tolerance regime, like the reference's own fp64 pipeline at those sets.
+    if constexpr (PRIO) TFHE_PRIO(3);
     constexpr bool kSmall = (BGBIT - 1) + 31 + 10 + (L == 1 ? 1 : L == 2 ? 2 : 3) < 51;
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -337,7 +348,12 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 // two workgroups per CU land as [2 0 1 1] waves per SIMD, one SIMD idle), so launches of 1..2 workgroups per
 // CU use this form: one 4-wave workgroup per CU = [1 1 1 1].  The two items only share the barriers.
 // (Three waves per SIMD do not fit this kernel's registers: profiles/r02_e_occupancy.txt.)
-template <int L, int BGBIT, int ITEMS = 1>
+//
+// FULL (launches of 769...1,024 bootstraps = two such workgroups on every CU, two waves per SIMD): the one-barrier step
+// (ALT) and the phase priorities (PRIO) of external_product_core.  Until late in round 3 this shape ran FOUR bootstraps in
+// one eight-wave workgroup, all in step on the key stream (5.84 ms); two free-running four-wave workgroups were slower
+// without priorities (6.27) and are faster with them: 5.93 -> 5.45 ms interleaved on one box (-8 %).
+template <int L, int BGBIT, int ITEMS = 1, bool FULL = false>
 __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs A)
 {
     constexpr int N = 1024;
@@ -394,9 +410,8 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
         const DiffSource S{accL[p], at, nullptr};
-        constexpr bool kAlt = ITEMS == 4;                 // see external_product_core
-        const int mine = kAlt ? p ^ (i & 1) : p;
-        external_product_core<L, BGBIT, kAlt>(S, e, key + (size_t)i * kStep, K, sc[mine], sc[mine ^ 1], A.tw, tw, A.offset, p, lane, clk);
+        const int mine = FULL ? p ^ (i & 1) : p;          // see external_product_core (ALT)
+        external_product_core<L, BGBIT, FULL, FULL>(S, e, key + (size_t)i * kStep, K, sc[mine], sc[mine ^ 1], A.tw, tw, A.offset, p, lane, clk);
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
         for (int q = 0; q < 16; q++) lds_add(&accL[p][64 * q + lane], e[q]);

@@ -312,11 +312,24 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
     const TwStep ts{expand_pow_once(tw.l2), expand_pow_once(tw.l3)};
     PhaseClock clk;
     clk.start();
+    // Issue priorities by phase (s_setprio), for the launches with two waves per SIMD (two free-running workgroups per CU,
+    // or the eight waves of the extended-table form): extract 3, forward
+    // exchanges 1, last forward level + products + gather 0, inverse exchanges 2, last inverse level + half swap 0, update 3.
+    // The two waves of a SIMD belong to different workgroups and are rarely in the same phase; the arbiter then favours
+    // the wave whose phase ends in a barrier three other waves wait at, and keeps the two workgroups out of step (one in
+    // its LDS-heavy exchanges while the other issues fp64).  Uint5 x 512: 5.85 -> 5.21 ms (profiles/r03_n_phase_priorities.txt;
+    // equal priorities for all phases 5.65, none 5.85).  At one workgroup per CU there is nothing to arbitrate and the
+    // s_setprio instructions only cut the scheduling regions (4.19 -> 4.42 ms at 256): KEYS_FIRST instances run without.
+    // With the builtins in the loop its 15 wave-uniform level-1 twiddle loads per step are vector loads again (see
+    // TFHE_PRIO in negacyclic_fft.hpp; tests/test_codegen.py carries the counts): measured, that costs less than it gains.
+    // Extended tables (EXT = 2, one eight-wave workgroup per CU): 6.09 -> 5.87 ms at 64.
+    constexpr bool kPhasePrio = !KEYS_FIRST;
     auto steps = [&](auto half_tag) {
     constexpr int H = decltype(half_tag)::value;        // = h, as a constant: the two hand-over patterns below are
                                                         // static per instance instead of 32 v_cndmask per step
     for (int i = 0; i < A.nsteps; i++) {
         int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        if constexpr (kPhasePrio) TFHE_PRIO(3);          // extract
         const uint32_t *Trot = T;                       // table the rotated operand is read from
         if constexpr (EXT > 1) {
             int src;
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
 #pragma unroll
             for (int q = 0; q < 4; q++) { y[4 + q] = keep[q]; y[q] = drecv[q * 64 + lane]; }
         }
-        fft512_forward(y, sc[w], table, tw, ts, lane);
+        fft512_forward<kPhasePrio ? 1 : -1, 0>(y, sc[w], table, tw, ts, lane);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if constexpr (!KEYS_FIRST) { kk[k] = kKeep[k * 64]; ks[k] = kSend[k * 64]; }
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
 #pragma unroll
         for (int k = 0; k < 8; k++) y[k] = y[k] + sc[wpart][k * 64 + lane];
         clk.mark(4);
-        fft512_inverse(y, sc[wpart], table, tw, ts, lane);  // table carries conj(c1)/1024
+        fft512_inverse<kPhasePrio ? 2 : -1, 0>(y, sc[wpart], table, tw, ts, lane);  // table carries conj(c1)/1024
         // undo the radix-2 level, x[a] = y0[a] + y1[a], x[a+8] = conj(rho)(y0[a] - y1[a]), for the wave's OWN points
         // a = 4h + q: it sends the sibling's four values and receives its own four -- half the traffic of exchanging
         // all eight, and both waves do the same work
@@ -390,6 +403,7 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
         clk.mark(6);
         __syncthreads();
         clk.mark(7);
+        if constexpr (kPhasePrio) TFHE_PRIO(3);          // update
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const cd o = srecv[q * 64 + lane], m = mine[q];

@@ -72,6 +72,10 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
 // early and its latency overlaps the other waves' fp64 work: -4 % blind-rotate time on the batched forward
 // exchanges; the same on the inverse / partner exchanges measured +3 %, so only the forward path uses it.
 #define TFHE_PRIO(n) __builtin_amdgcn_s_setprio(n)
+// (s_setprio has unmodelled side effects: like a volatile asm -- expand_pow below -- it counts as a store to anything when
+// LLVM decides whether a wave-uniform load may be a scalar load.  Tying the instruction to a live register with a
+// non-volatile asm keeps the loads scalar but lets the instruction float; where both were measured -- k_blind_rotate_2048's
+// phase priorities -- the builtin's fixed position was worth more than the scalar loads, 5.22 vs 5.29 ms.)
 // LDS-exchange scheduling (r02; A/B on one box, tools/ab_bench.py): the exchanges' DS instructions are spread
 // through the arithmetic with sched_group_barrier instead of being issued in bursts -- the waves of these kernels
 // spent ~20 % of their cycles stalled on the LDS instruction queue (SQ_WAIT_INST_LDS), a burst of ds_write_b128
@@ -254,11 +258,15 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
         __builtin_amdgcn_sched_barrier(0);                                        \
     } while (0)
 #define FFT_MIX1_BEGIN() __builtin_amdgcn_sched_barrier(0)
+// PRIO_IN >= 0: the wave runs the transform's two exchange levels at issue priority PRIO_IN and its last level (and
+// whatever follows) at PRIO_OUT -- the phase priorities of k_blind_rotate_2048 (kernels_n2048.hpp).  -1: no s_setprio.
+template <int PRIO_IN = -1, int PRIO_OUT = 0>
 __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                const LaneTwiddles &tw, const TwStep &ts, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
     FFT_MIX1_BEGIN();
+    if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_IN);
 #pragma unroll
     for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
     dft8<1>(x);
@@ -278,14 +286,17 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     for (int c = 0; c < 8; c++) x[c] = sc[SL2R(c)];
     wave_lds_order();
     FFT_MIX1(64);
+    if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_OUT);
     twist_all(x, tw.l3, ts.l3);
     dft8<1>(x);
 }
+template <int PRIO_IN = -1, int PRIO_OUT = 0>
 __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                const LaneTwiddles &tw, const TwStep &ts, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
     FFT_MIX1_BEGIN();
+    if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_IN);
     dft8<-1>(x);
     twist_all_conj(x, tw.l3, ts.l3);
 #pragma unroll
@@ -304,6 +315,7 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
     for (int m = 0; m < 8; m++) x[m] = sc[SL1W(m)];
     wave_lds_order();
     FFT_MIX1(64);
+    if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_OUT);
     dft8<-1>(x);
 #pragma unroll
     for (int a = 0; a < 8; a++) x[a] = cmul(x[a], table[8 + a]);
