@@ -111,11 +111,11 @@ def balance_levels(levels, width):
 
 def launch_cost_ms(bootstraps, full=1024):
     """Measured time of one level of `bootstraps` gate bootstraps on one MI355X (blind rotate + key switch, 128-bit set,
-    profiles/r03_*): a step function of the launch shape -- up to 256 (one bootstrap per CU) run the eight-wave
-    kernel, up to 512 the two-wave kernel with two bootstraps per four-wave workgroup, then the two-wave kernel at three
-    (one per workgroup) and four (four per eight-wave workgroup) bootstraps per CU; longer levels are full launches
-    plus a tail."""
-    steps = ((256, 2.57), (512, 4.04), (768, 5.42), (1024, 5.97))
+    profiles/r03_n_phase_priorities.txt, one box): a step function of the launch shape -- up to 256 (one bootstrap per CU)
+    run the eight-wave kernel, up to 512 the two-wave kernel with two bootstraps per four-wave workgroup (one per CU), then
+    three two-wave workgroups per CU, then two four-wave workgroups per CU (both with phase priorities); longer levels are
+    full launches plus a tail."""
+    steps = ((256, 2.60), (512, 4.05), (768, 4.95), (1024, 5.78))
     n_full, rem = divmod(int(bootstraps), full)
     t = n_full * steps[-1][1]
     if rem:

@@ -49,7 +49,8 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         //                    the key stream (rounds 1-3), 6.27 for the same two workgroups without priorities;
         //   257..512  items: one such workgroup per CU: the hardware leaves a SIMD idle with two 2-wave
         //                    workgroups per CU (see k_blind_rotate), 5.15 -> 4.42 ms at 512;
-        //   513..768  items: one item per workgroup (pairing measured 6.40 vs 5.65 ms at 768).
+        //   513..768  items: one item per workgroup (pairing measured 6.40 vs 5.65 ms at 768), with the phase priorities:
+        //                    5.26 -> 4.57 ms at 768.
         if (shape_is_1024(shape) && cnt > 3 * num_cus) {
             const dim3 g2((cnt + 1) / 2);
             switch (shape) {
@@ -65,6 +66,14 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
             case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6, 2>), g2, dim3(256), 0, st, a); break;
             case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10, 2>), g2, dim3(256), 0, st, a); break;
             default: hipLaunchKernelGGL((k_blind_rotate<1, 23, 2>), g2, dim3(256), 0, st, a); break;
+            }
+            continue;
+        }
+        if (shape_is_1024(shape) && cnt > 2 * num_cus) {        // 513..768: three two-wave workgroups per CU, phase priorities
+            switch (shape) {
+            case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate<3, 6, 1, true>), g, dim3(128), 0, st, a); break;
+            case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10, 1, true>), g, dim3(128), 0, st, a); break;
+            default: hipLaunchKernelGGL((k_blind_rotate<1, 23, 1, true>), g, dim3(128), 0, st, a); break;
             }
             continue;
         }

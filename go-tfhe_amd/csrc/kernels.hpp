@@ -349,8 +349,9 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 // CU use this form: one 4-wave workgroup per CU = [1 1 1 1].  The two items only share the barriers.
 // (Three waves per SIMD do not fit this kernel's registers: profiles/r02_e_occupancy.txt.)
 //
-// FULL (launches of 769...1,024 bootstraps = two such workgroups on every CU, two waves per SIMD): the one-barrier step
-// (ALT) and the phase priorities (PRIO) of external_product_core.  Until late in round 3 this shape ran FOUR bootstraps in
+// FULL = the launch puts two waves from DIFFERENT workgroups on a SIMD: 769...1,024 bootstraps as two four-wave workgroups
+// per CU (ITEMS = 2: the one-barrier step ALT and the phase priorities PRIO of external_product_core), 513...768 as three
+// two-wave workgroups per CU (ITEMS = 1: the priorities only -- ALT measured the same there): 5.26 -> 4.57 ms at 768.  Until late in round 3 this shape ran FOUR bootstraps in
 // one eight-wave workgroup, all in step on the key stream (5.84 ms); two free-running four-wave workgroups were slower
 // without priorities (6.27) and are faster with them: 5.93 -> 5.45 ms interleaved on one box (-8 %).
 template <int L, int BGBIT, int ITEMS = 1, bool FULL = false>
@@ -410,8 +411,9 @@ __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
         uint32_t e[16];
         const DiffSource S{accL[p], at, nullptr};
-        const int mine = FULL ? p ^ (i & 1) : p;          // see external_product_core (ALT)
-        external_product_core<L, BGBIT, FULL, FULL>(S, e, key + (size_t)i * kStep, K, sc[mine], sc[mine ^ 1], A.tw, tw, A.offset, p, lane, clk);
+        constexpr bool kAlt = FULL && ITEMS == 2;         // the one-barrier step: see external_product_core (ALT)
+        const int mine = kAlt ? p ^ (i & 1) : p;
+        external_product_core<L, BGBIT, kAlt, FULL>(S, e, key + (size_t)i * kStep, K, sc[mine], sc[mine ^ 1], A.tw, tw, A.offset, p, lane, clk);
         // acc += e   (evaluator.go:102-105)
 #pragma unroll
         for (int q = 0; q < 16; q++) lds_add(&accL[p][64 * q + lane], e[q]);

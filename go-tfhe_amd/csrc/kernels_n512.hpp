@@ -171,6 +171,7 @@ __device__ __forceinline__ void external_product_core_512(F coef, uint32_t (&e)[
 {
     constexpr uint32_t mask = (1u << BGBIT) - 1u;
     constexpr int half = 1 << (BGBIT - 1), shift = 32 - BGBIT;
+    TFHE_PRIO(3);                        // phase priorities: see k_blind_rotate_512
     cd ka[8], kb[8];
     const cd *kp = key_i + (size_t)h * 2 * 256 + hl;
 #pragma unroll
@@ -184,14 +185,18 @@ __device__ __forceinline__ void external_product_core_512(F coef, uint32_t (&e)[
         const uint32_t d0 = coef(32 * a + hl) + offset, d1 = coef(32 * a + hl + 256) + offset;
         x[a] = cd{(double)((int)((d0 >> shift) & mask) - half), (double)((int)((d1 >> shift) & mask) - half)};
     }
+    TFHE_PRIO(1);
     fft256_forward(x, sch, table, tw, hl);
+    TFHE_PRIO(0);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         cd pa = cmul(x[k], ka[k]), pb = cmul(x[k], kb[k]);
         swap_halves(pa, pb);
         x[k] = pa + pb;
     }
+    TFHE_PRIO(2);
     fft256_inverse(x, sch, table, tw, hl);
+    TFHE_PRIO(3);
 #pragma unroll
     for (int a = 0; a < 8; a++) {
         e[a] = round_to_torus_wide(x[a].re);
@@ -200,7 +205,10 @@ __device__ __forceinline__ void external_product_core_512(F coef, uint32_t (&e)[
 }
 
 // evaluator.BlindRotateAssign (evaluator.go:110-135) with the gate prep / mod-switch prologue of
-// k_blind_rotate.  grid = batch, block = 64 (one wavefront).
+// k_blind_rotate.  grid = batch, block = 64 (one wavefront).  Eight of these single-wave workgroups share a CU at full
+// launches, two per SIMD and free-running; external_product_core_512 sets an issue priority per phase (key requests +
+// decomposition 3, forward transform 1, products 0, inverse transform 2, rounding + update 3: see external_product_core in
+// kernels.hpp): Uint2 x 2,048: 3.04 -> 2.71 ms (-11 %), bit-identical (profiles/r03_n_phase_priorities.txt).
 template <int BGBIT>
 __global__ __launch_bounds__(64, 2) void k_blind_rotate_512(BlindRotateArgs A)
 {

@@ -24,6 +24,7 @@ EXPECT = {
     "k_blind_rotate<3, 6, 2, true>": (15, 54, 256, 8),    # headline kernel (full launches); 8 bytes of scratch are outside the loop
     "k_blind_rotate<3, 6, 2, false>": (15, 54, 256, 0),
     "k_blind_rotate<3, 6, 1, false>": (15, 54, 256, 20),
+    "k_blind_rotate<3, 6, 1, true>": (15, 54, 256, 24),
     "k_blind_rotate<2, 10, 2, true>": (15, 38, 256, 0),
     "k_blind_rotate<1, 23, 2, true>": (15, 22, 256, 0),
     "k_blind_rotate_oct<3, 6>": (16, 33, 256, 0),
