@@ -175,7 +175,7 @@ def measured_ceilings():
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-# VALU instructions a wave of k_blind_rotate<3,6,4> issues per CMUX step (SQ_INSTS_VALU / waves / steps of the committed
+# VALU instructions a wave of k_blind_rotate<3,6,2,FULL> (the full-launch form) issues per CMUX step (SQ_INSTS_VALU / waves / steps of the committed
 # rocprofv3 PMC pass, profiles/r03_i_pmc_summary.txt: 2.1465e9 / 2048 / 700) and its occupancy: what `roofline.attainable`
 # is computed from
 BR_VALU_PER_WAVE_STEP = 1497
@@ -298,7 +298,7 @@ def extra_configs(pkg, key, ck, dev):
             "workload": "BASELINE configs[4], one GPU's share (1/8 of the 1M-gate stream): 131,072 mixed AND/OR/XOR/MUX gates on a pool of "
                         "encrypted bits, 128-bit params; MUX = 3 bootstraps (gates.go:107-114), split on the device",
             "gates": total, "bootstraps": nb, "seconds": dt, "rate": total / dt, "unit": "gates/s", "bootstraps_per_s": nb / dt,
-            "dominant_kernel": "k_blind_rotate<3,6,4>", **kernel_part(kt, 1, nb, pkg.params.Security128Bit),
+            "dominant_kernel": "k_blind_rotate<3,6,2,FULL>", **kernel_part(kt, 1, nb, pkg.params.Security128Bit),
             "verified": dec_ok and bit_ok,
             "checks": {"4096_sampled_outputs_decrypt_correctly": dec_ok, "one_gate_of_each_kind_bit_identical_to_oracle": bit_ok}}
         del a, b, c, res_t, pool
