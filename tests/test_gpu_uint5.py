@@ -70,7 +70,8 @@ def test_blind_rotate_every_step_within_tolerance_of_exact_cmux(oracle, keys_u5_
     exact-integer CMUX increment bsk[k] (x) (X^a~_k * acc_k - acc_k), within the stated per-product tolerance of 2^9 per
     coefficient.  (Across several steps two correct fp64 pipelines diverge -- digits flip -- so a whole chain is only
     comparable at the decrypt level; one step from the kernel's own previous state is comparable exactly.)
-    B = 3 runs one bootstrap per workgroup, B = 260 two per eight-wave workgroup (more than one per CU)."""
+    B = 3 runs the instance for at most one workgroup per CU (key slices requested at the top of the step), B = 260 the
+    instance for two free-running workgroups per CU (phase priorities)."""
     k = keys_u5_small
     p, N = k.p, 2048
     rs = np.random.RandomState(41)
