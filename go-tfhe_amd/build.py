@@ -30,22 +30,34 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         print(f"[build] {os.path.relpath(LIB_PATH)}: up to date with csrc/ (reused)", file=sys.stderr)
         return LIB_PATH
-    print(f"[build] compiling {', '.join(x for x, _ in SOURCES)} for gfx950 -> {os.path.relpath(LIB_PATH)}", file=sys.stderr, flush=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    procs = []
-    for src, extra in SOURCES:
-        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
+    # Several ranks of one node may import the package at once (torch.distributed.run): one of them builds, the others wait
+    # on the lock and then find the library up to date.  Objects and library are written under private names and renamed.
+    import fcntl
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            print(f"[build] {os.path.relpath(LIB_PATH)}: built by another process meanwhile (reused)", file=sys.stderr)
+            return LIB_PATH
+        print(f"[build] compiling {', '.join(x for x, _ in SOURCES)} for gfx950 -> {os.path.relpath(LIB_PATH)}", file=sys.stderr, flush=True)
+        tag = f".{os.getpid()}.tmp"
+        objs = []
+        procs = []
+        for src, extra in SOURCES:
+            obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+            cmd = [HIPCC] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj + tag]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        for cmd, pr in procs:
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        for obj in objs:
+            os.replace(obj + tag, obj)
+        link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH + tag]
         if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for cmd, pr in procs:
-        if pr.wait() != 0:
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(link))
-    subprocess.run(link, check=True)
+            print(" ".join(link))
+        subprocess.run(link, check=True)
+        os.replace(LIB_PATH + tag, LIB_PATH)
     return LIB_PATH
