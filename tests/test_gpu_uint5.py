@@ -298,11 +298,13 @@ def test_wide_keyswitch_full_dimension(oracle, keys_u5_full, ck_u5_full):
 
 
 @pytest.mark.parametrize("name,B", [("uint5", 63), ("uint5", 64), ("uint5", 256), ("uint5", 513),
-                                    ("uint2", 63), ("uint2", 65), ("uint2", 2047), ("uint2", 2049)])
+                                    ("uint2", 63), ("uint2", 65), ("uint2", 2047), ("uint2", 2049),
+                                    ("uint1", 600), ("uint1", 1023), ("uint3", 769), ("uint3", 1025)])
 def test_dispatch_boundaries_uint_shapes(oracle, pkg, name, B):
     # gather / wide key switch (64), full launch (512 at N=2048, 2048 at N=512) and chunking: key switch
-    # bit-exact, PBS decrypts correctly for every item
-    modulus = {"uint5": 32, "uint2": 4}[name]
+    # bit-exact, PBS decrypts correctly for every item.  Uint1 / Uint3 (N = 1024, L = 2 / 1): the launch shapes with two
+    # waves per SIMD from different workgroups -- 513...768 and 769...1,024 bootstraps -- i.e. the phase-priority instances
+    modulus = {"uint5": 32, "uint2": 4, "uint1": 2, "uint3": 8}[name]
     k = KeySet(oracle, name, 0x7F4E000C, n_override=40, torus=False)
     ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
     rs = np.random.RandomState(2000 + B)
