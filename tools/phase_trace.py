@@ -46,9 +46,9 @@ print("mean (std) over the launch's items:")
 for w in range(W):
     print(f"w{w}    " + "".join(f"{v:10.0f}" for v in m[w]) + f"{m[w].sum():10.0f}")
     print("      " + "".join(f"{'(%d)' % v:>10s}" for v in sd[w]))
-if not oct_kernel and not n2048 and B % 4 == 0:
-    print("mean by position of the item in a four-item workgroup (launches of > 3 bootstraps per CU):")
-    for pos in range(4):
+if not oct_kernel and not n2048 and B % 2 == 0:
+    print("mean by position of the item in a two-item workgroup (launches of more than one bootstrap per CU):")
+    for pos in range(2):
         for w in range(W):
-            mm = t[pos::4, w].mean(axis=0)
+            mm = t[pos::2, w].mean(axis=0)
             print(f"i{pos} w{w} " + "".join(f"{v:10.0f}" for v in mm) + f"{mm.sum():10.0f}")
