@@ -556,7 +556,9 @@ def main():
                 line["roofline"]["attainable_note"] = (
                     f"fp64 Tflop/s if the kernel's {BR_VALU_PER_WAVE_STEP} VALU instructions per wave and CMUX step issued at the rate "
                     f"tools/ubench_ceilings measured on this box for {BR_WAVES_PER_SIMD} resident waves per SIMD ({ns:.3f} ns per instruction per SIMD; "
-                    "the nominal peak assumes one every 4 cycles and 2 flop per lane, an FFT's mix is 1.42)")
+                    "the nominal peak assumes one every 4 cycles and 2 flop per lane, an FFT's mix is 1.42); the microbenchmark is short, "
+                    "the blind rotate itself runs power-limited -- ~1.36 kW of the board's 1.4 kW, shader clock ~2.26 GHz instead of 2.4 "
+                    "(profiles/r03_p_clock_power.txt) -- so the ceiling at the clock the kernel gets is ~6 % lower than this figure")
                 # the kernel's other pipe: DS instructions per wave and CMUX step (by kind; from the source and SQ_INSTS_LDS of the
                 # committed PMC pass) x their measured cost on this box x the eight resident waves of a CU, over the step's time
                 ld = ceil["lds_ns_per_wave_instr_per_cu"]
