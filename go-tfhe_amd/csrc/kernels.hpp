@@ -351,9 +351,10 @@ __device__ __forceinline__ void external_product_core(const DiffSource &S, uint3
 //
 // FULL = the launch puts two waves from DIFFERENT workgroups on a SIMD: 769...1,024 bootstraps as two four-wave workgroups
 // per CU (ITEMS = 2: the one-barrier step ALT and the phase priorities PRIO of external_product_core), 513...768 as three
-// two-wave workgroups per CU (ITEMS = 1: the priorities only -- ALT measured the same there): 5.26 -> 4.57 ms at 768.  Until late in round 3 this shape ran FOUR bootstraps in
-// one eight-wave workgroup, all in step on the key stream (5.84 ms); two free-running four-wave workgroups were slower
-// without priorities (6.27) and are faster with them: 5.93 -> 5.45 ms interleaved on one box (-8 %).
+// two-wave workgroups per CU (ITEMS = 1: the priorities only -- ALT measured the same there): 5.26 -> 4.57 ms at 768.
+// Until late in round 3 the full launch ran FOUR bootstraps in one eight-wave workgroup, all in step on the key stream
+// (5.84 ms); two free-running four-wave workgroups were slower without priorities (6.27) and are faster with them:
+// 5.87 -> 5.33 ms interleaved on one box (-9 %; profiles/r03_n_phase_priorities.txt).
 template <int L, int BGBIT, int ITEMS = 1, bool FULL = false>
 __global__ __launch_bounds__(128 * ITEMS, 2) void k_blind_rotate(BlindRotateArgs A)
 {
