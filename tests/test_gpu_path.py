@@ -208,6 +208,30 @@ def test_full_size_batch_1024_nand_128bit(oracle, keys128, ck128):
     assert np.array_equal(ck128.ctx.gate_batch("NAND", a, b), out)
 
 
+@pytest.mark.parametrize("B", [700, 1024, 5000])
+def test_batch_position_does_not_matter_128bit(keys128, ck128, B):
+    # size-independent property at and above BASELINE config 2's size: a bootstrap's output words depend on its own inputs
+    # only -- permuting the batch permutes the outputs bit for bit, and a slice of the batch run on its own gives the same
+    # words.  Items change workgroup, partner item, launch (5000 = four full launches + a 904-item one) and, between the
+    # full batch and the slice, kernel shape (two free-running workgroups per CU / three / the eight-wave kernel).
+    k = keys128
+    rs = np.random.RandomState(4100 + B)
+    pool_a, pool_b = k.enc(rs.randint(0, 2, 64)), k.enc(rs.randint(0, 2, 64))
+    ia, ib = rs.randint(0, 64, B), rs.randint(0, 64, B)
+    a, b = pool_a[ia], pool_b[ib]
+    out = ck128.ctx.gate_batch("XOR", a, b)
+    perm = rs.permutation(B)
+    assert np.array_equal(ck128.ctx.gate_batch("XOR", a[perm], b[perm]), out[perm])
+    cut = slice(B // 3, B // 3 + 200)
+    assert np.array_equal(ck128.ctx.gate_batch("XOR", a[cut], b[cut]), out[cut])
+    # equal inputs give equal outputs wherever they sit in the batch
+    first = {}
+    for i, key in enumerate(zip(ia, ib)):
+        j = first.setdefault(key, i)
+        if j != i:
+            assert np.array_equal(out[i], out[j]), (i, j)
+
+
 def test_edge_cases_and_errors(pkg, keys_small, ck_small):
     from conftest import gpu_params
     k = keys_small
