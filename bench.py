@@ -19,10 +19,14 @@ the HBM streaming figure BASELINE.json's metric asks for is reported beside it (
 `cpu_baseline` (N=1, rank 0) times the C oracle (a port of the Go reference, which cannot run here:
 no Go toolchain) on the host cores over a bounded sample of the same gates.
 
---mode sharded times the path the north star names for multi-GPU work that starts on ONE rank:
-root holds the batch, scatter -> local gate batch -> gather inside the timed region
-(--workload mixed: BASELINE config 5, AND/OR/XOR/MUX stream; --workload adder: config 3, the 40-gate
-ripple-carry adder sharded by circuit); it prints scatter / compute / gather milliseconds separately.
+With N > 1 ranks (the command the driver runs for the scaling curve) the weak-scaling headline is followed, on the same
+process group, by the two BASELINE configs that are DEFINED as multi-GPU workloads, in the form the north star names -- the
+batch starts on ONE rank: scatter -> local path -> gather, all timed -- configs[4] (1,048,576 mixed AND/OR/XOR/MUX gates,
+contiguous shards) and configs[2] (the 40-gate ripple-carry adder x 256, sharded by circuit), each verified, with scatter /
+compute / gather milliseconds and, per rank, the shader clock and socket power sampled DURING the timed loops (the blind
+rotate runs power-limited; a sub-linear curve must be attributable).  The default process group is gloo (host barriers, timing
+reduce); the data path uses an RCCL group that all ranks agree on by handshake, or gloo through host memory if RCCL is unusable
+on any rank.  `--mode sharded` runs one of these workloads alone (any rank count, --gates sets the stream length).
 """
 import argparse
 import json
@@ -50,6 +54,33 @@ def measured_traffic(kernel):
     try:
         rec = json.load(open(PMC_FILE))[kernel]
         return rec["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def traffic_source():
+    """Where `roofline.traffic` comes from: the committed PMC file and the commit that last changed it (None when git is absent,
+    as on the GPU box -- the file name alone then)."""
+    import subprocess
+    rel = os.path.relpath(PMC_FILE, ROOT)
+    try:
+        c = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cs", "--", rel], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:
+        c = ""
+    try:
+        meta = json.load(open(PMC_FILE)).get("_meta")
+    except Exception:
+        meta = None
+    return {"file": rel, "file_commit": c or None, "collected": meta,
+            "how": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (tools/prof_pmc.sh), 2 x FETCH_SIZE + WRITE_SIZE in KiB "
+                   "(gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM); a committed measurement, NOT collected by this run"}
+
+
+def measured_traffic_uint5(kernel):
+    """The same for the Uint5 x 512 run (profiles/pmc_traffic_uint5.json: FETCH_SIZE / WRITE_SIZE of k_keyswitch_wide<6> and
+    k_blind_rotate_2048), raw and corrected, or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_uint5.json")))[kernel]
     except Exception:
         return None
 
@@ -175,14 +206,25 @@ def measured_ceilings():
         return {"error": f"{type(e).__name__}: {e}"}
 
 
-# VALU instructions a wave of k_blind_rotate<3,6,2,FULL> (the full-launch form) issues per CMUX step (SQ_INSTS_VALU / waves / steps of the committed
-# rocprofv3 PMC pass, profiles/r03_i_pmc_summary.txt: 2.1465e9 / 2048 / 700) and its occupancy: what `roofline.attainable`
-# is computed from
-BR_VALU_PER_WAVE_STEP = 1497
+# VALU instructions a wave of k_blind_rotate<3,6,2,FULL> (the full-launch form) issues per CMUX step and its occupancy: what
+# `roofline.attainable` is computed from.  A STATIC count of the compiled step loop, which tests/test_codegen.py re-derives from the
+# gfx950 assembly on every CPU-tier run (+-2) -- and equal to SQ_INSTS_VALU / waves / steps of the committed rocprofv3 PMC pass
+# (profiles/r03_p_pmc_summary.txt: 2.1437e9 / 2,048 / 700 = 1,495).  Changing the kernel without updating these fails the CPU tier.
+BR_KERNEL = "k_blind_rotate<3, 6, 2, true>"
+BR_VALU_PER_WAVE_STEP = 1495
 BR_WAVES_PER_SIMD = 2
-# ... and its DS instructions per wave and step: 4 transforms x 2 exchanges x 8 + 8 (product hand-over) 16-byte stores and as many
-# loads, 32 accumulator reads, 16 accumulator adds (192; SQ_INSTS_LDS / waves / steps = 186: a few accumulator reads pair up)
-BR_DS_PER_WAVE_STEP = {"ds_write_b128": 72, "ds_read_b128": 72, "ds_read_b32": 32, "ds_add_u32": 16}
+# ... and its DS instructions per wave and step, by opcode as compiled (186 in all = SQ_INSTS_LDS / waves / steps): 4 transforms x 2
+# exchanges x 8 + 8 (product hand-over) 16-byte stores and as many loads; 32 accumulator words read as 18 ds_read_b32 + 7 paired
+# ds_read2st64_b32; the mod-switched rotation amount (ds_read_u16); 16 accumulator adds.  tests/test_codegen.py pins every count.
+BR_DS_PER_WAVE_STEP = {"ds_write_b128": 72, "ds_read_b128": 72, "ds_read_b32": 18, "ds_read2st64_b32": 7, "ds_read_u16": 1, "ds_add_u32": 16}
+# tools/ubench_ceilings measures four DS kinds; the other two are priced as multiples of ds_read_b32 (a paired read moves two words)
+BR_DS_PRICED_AS = {"ds_read2st64_b32": ("ds_read_b32", 2.0), "ds_read_u16": ("ds_read_b32", 1.0)}
+
+
+def ds_cost_ns(kind, measured):
+    """Measured CU time of one wave-instruction of this DS kind (ns), through BR_DS_PRICED_AS where it was not measured itself."""
+    base, mult = BR_DS_PRICED_AS.get(kind, (kind, 1.0))
+    return measured[base] * mult
 
 
 class KernelTimer:
@@ -201,7 +243,7 @@ class KernelTimer:
         self.ks_n, self.ks_ms = self.ctx.timing_read(1)
 
 
-def extra_configs(pkg, key, ck, dev):
+def extra_configs(pkg, key, ck, dev, ceil=None):
     """BASELINE configs 3, 4 and 5 (one GPU's share) AFTER the headline's timed region: each with its own timed loop, the
     blind-rotate share of it, that kernel family's fp64 fraction, and `verified` from checks done outside the timed loops
     (decrypt-level for everything, bit-equality with the oracle on samples where the parameter set is exact)."""
@@ -336,6 +378,7 @@ def extra_configs(pkg, key, ck, dev):
                         "(n=1071, N=2048, L=1, Bgbit=22), LUT x mod 16 over Z_32, batch 512; cloud key generated on the GPU",
             "pbs": B, "seconds": dt, "rate": B / dt, "unit": "PBS/s", "dominant_kernel": "k_blind_rotate_2048<22>",
             **kernel_part(kt, 10, B, p5),
+            "keyswitch": keyswitch_hbm_record(p5, B, kt.ks_ms / 10, ceil),
             "verified": dec_ok and phase_ok,
             "checks": {"all_512_decrypt_to_lut_of_message": dec_ok, "output_phase_within_2^32/(4*32)_of_ideal": phase_ok,
                        "max_phase_distance": int(dist.max()),
@@ -348,16 +391,95 @@ def extra_configs(pkg, key, ck, dev):
     return out
 
 
+def keyswitch_hbm_record(p, B, ks_ms, ceil):
+    """The one kernel of the path that HBM binds: the Uint5 key switch (k_keyswitch_wide<6>, trgsw/keyswitch.go:10-37) walks a
+    1.66 GB table -- six times the Infinity Cache -- exactly once per launch.  Compulsory bytes = the packed table (the all-zero k = 0
+    rows dropped, rows padded to 16 B: [N][t][base-1][n1p] words) + the extracted accumulators in + the LWE samples out; measured
+    bytes from the committed rocprofv3 PMC pass of the same launch."""
+    n1p = (p.n + 1 + 3) // 4 * 4
+    table = p.N * p.t * (p.base - 1) * n1p * 4
+    io = B * (p.N + 1) * 4 + B * (p.n + 1) * 4           # A polynomial + body word in, LWE out
+    comp = table + io
+    gbs = comp / (ks_ms * 1e-3) / 1e9 if ks_ms else None
+    rec = {"kernel": f"k_keyswitch_wide<{p.basebit}> (+ extract)", "ms": ks_ms, "compulsory_bytes": comp, "table_bytes": table, "io_bytes": io,
+           "GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS if gbs else None, "hbm_peak_GBps": HBM_PEAK_GBS}
+    try:
+        copy = ceil["hbm_copy"]["kernel_copy_GBps"]
+        rec["measured_copy_GBps"] = copy
+        rec["frac_of_measured_copy"] = gbs / copy
+    except Exception:
+        pass
+    m = measured_traffic_uint5("k_keyswitch")
+    if m:
+        rec["measured"] = {"FETCH_SIZE_KiB": m.get("FETCH_SIZE_KiB"), "WRITE_SIZE_KiB": m.get("WRITE_SIZE_KiB"),
+                           "hbm_bytes_per_launch": m.get("hbm_bytes_per_launch"), "correction": m.get("correction"),
+                           "ratio_to_compulsory": m["hbm_bytes_per_launch"] / comp if m.get("hbm_bytes_per_launch") else None,
+                           "source": "profiles/pmc_traffic_uint5.json (committed rocprofv3 PMC passes of tools/pmc_workload.py uint5 512; not collected by this run)"}
+    else:
+        rec["measured"] = None
+    return rec
+
+
+_JSON_FD = None
+
+
+def claim_stdout():
+    """From here on everything this process (Python, RCCL's version banner, gloo's "[Gloo] Rank 0 is connected ..." lines, any
+    library's printf) writes to fd 1 goes to stderr; the real stdout is kept aside for the ONE JSON line emit() prints."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
 def emit(line):
-    """The JSON line, as the LAST thing on stdout: RCCL printf()s a version banner into the C stdio buffer when a
-    communicator is created, which would otherwise be flushed behind it at process exit."""
+    """The JSON line, as the only thing on the real stdout (claim_stdout)."""
     import ctypes
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(line), flush=True)
+    data = (json.dumps(line) + "\n").encode()
+    fd = _JSON_FD if _JSON_FD is not None else 1
+    while data:
+        data = data[os.write(fd, data):]
+
+
+def init_distributed(rank, world, dev, want):
+    """Process groups of a multi-rank run.  Returns (dist, data_group, backend).
+
+    The DEFAULT group is gloo -- host-side barriers, the timing reduce, object gathers: it comes up whatever state RCCL
+    is in -- and the data path (key broadcast, batch scatter / gather) gets its own RCCL group.  Whether that group works
+    is decided by ALL ranks together: every rank tries one all-reduce on it, the outcomes are MIN-reduced over gloo, and
+    either every rank uses RCCL or every rank falls back to gloo through host memory (a per-rank fallback would leave the
+    ranks on different backends and hang at the first collective)."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+    if want != "nccl":
+        return dist, None, "gloo"
+    ok, err, group = 1, None, None
+    try:
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe, group=group)
+        torch.cuda.synchronize()
+        if int(probe.item()) != world:
+            raise RuntimeError(f"RCCL all-reduce probe returned {probe.item()} on {world} ranks")
+    except Exception as e:                                   # noqa: BLE001
+        ok, err = 0, f"{type(e).__name__}: {e}"
+    agreed = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)            # over gloo: the handshake itself cannot depend on RCCL
+    if int(agreed.item()) == 1:
+        return dist, group, "nccl"
+    print(f"[bench] rank {rank}: RCCL group unusable on at least one rank (this rank: {err or 'ok'}); ALL ranks use gloo "
+          "(key distribution, scatter and gather then go through host memory)", file=sys.stderr)
+    return dist, None, "gloo"
 
 
 def main():
@@ -370,7 +492,10 @@ def main():
     ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
     ap.add_argument("--workload", choices=["mixed", "adder"], default="mixed", help="--mode sharded only")
     ap.add_argument("--gates", type=int, default=0, help="--mode sharded --workload mixed: total gates (default 131072 per rank)")
+    ap.add_argument("--config5-gates", type=int, default=1048576,
+                    help="N > 1: size of the sharded mixed stream run after the headline (BASELINE configs[4] is 1M gates; smaller only for dry runs)")
     args = ap.parse_args()
+    claim_stdout()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -385,23 +510,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, group = None, None
     backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU dry runs of the N>1 path
     if world > 1 or args.mode == "sharded":
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl" and not share:
-            try:                                                 # eager communicator creation: a broken RCCL set-up fails HERE, on every rank
-                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-            except Exception as e:                               # keep the run alive over gloo: the data path has no collective anyway
-                print(f"[bench] rank {rank}: RCCL initialisation failed ({type(e).__name__}: {e}); falling back to gloo "
-                      "(key distribution and the timing reduce then go through host memory)", file=sys.stderr)
-                backend = "gloo"
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:                                                    # two ranks on one GPU cannot form an RCCL communicator
-            backend = "gloo"
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist, group, backend = init_distributed(rank, world, dev, backend if not share else "gloo")
 
     def barrier():
         if dist:
@@ -425,17 +537,15 @@ def main():
         from go_tfhe_amd.distributed import broadcast_cloud_key
         ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank) if rank == 0 else pkg.CloudKey(p, device=local_rank)
         via_host = backend != "nccl"
-        if not via_host:
-            torch.cuda.synchronize()
+        torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        broadcast_cloud_key(ck.ctx, src=0, via_host=via_host)     # a failure here is fatal: the other ranks hold no key material
+        broadcast_cloud_key(ck.ctx, src=0, group=group, via_host=via_host)     # a failure here is fatal: the other ranks hold no key material
         sk = torch.zeros(p.n + p.N, dtype=torch.int32, device=dev if not via_host else "cpu")
         if rank == 0:
             sk.copy_(torch.from_numpy(np.concatenate([key.s0, key.s1]).astype(np.int32)))
-        dist.broadcast(sk, src=0)
-        if not via_host:
-            torch.cuda.synchronize()
+        dist.broadcast(sk, src=0, group=group)
+        torch.cuda.synchronize()
         key_broadcast_ms = (time.perf_counter() - t0) * 1e3
         if rank != 0:
             skh = sk.cpu().numpy().astype(np.uint32)
@@ -443,9 +553,20 @@ def main():
     else:
         ck = pkg.CloudKey(p, bsk_fourier=key.bsk, ksk=key.ksk, device=local_rank)
     ctx = ck.ctx
+    env = DistEnv(dist, group, backend, rank, world, dev, local_rank)
     if args.mode == "sharded":
-        return sharded_mode(args, pkg, p, key, ck, dist, backend, rank, world, dev)
+        if args.workload == "mixed":
+            rec = sharded_mixed(pkg, p, key, ck, env, args.gates or 131072 * world, args.steps, max(1, args.warmup))
+        else:
+            rec = sharded_adder(pkg, p, key, ck, env, args.steps, max(1, args.warmup))
+        ck.close()
+        dist.destroy_process_group()
+        if rank == 0:
+            emit({"metric": "gate bootstraps/sec, batch held by rank 0 (scatter + compute + gather timed)", "mode": "sharded",
+                  "value": rec["rate"], "higher_is_better": True, "scaling": "strong", **rec})
+        return
 
+    from go_tfhe_amd import telemetry
     rs = np.random.RandomState(KEY_SEED + rank)
     bits_a, bits_b = rs.randint(0, 2, BATCH), rs.randint(0, 2, BATCH)
     a_h, b_h = key.enc(bits_a, 1000 + 2 * rank), key.enc(bits_b, 1001 + 2 * rank)
@@ -468,16 +589,18 @@ def main():
     torch.cuda.synchronize()
     out.zero_()                                          # the check below reads what the TIMED steps wrote
     torch.cuda.synchronize()
+    sampler = telemetry.Sampler(local_rank, period_s=0.005)
     barrier()
     torch.cuda.synchronize()
     ctx.timing_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    with sampler:                                        # a thread reading two SMI values every 5 ms; nothing on the launch path
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
     ctx.timing_enable(False)
     br_n, br_ms = ctx.timing_read(0)
     ks_n, ks_ms = ctx.timing_read(1)
@@ -490,14 +613,23 @@ def main():
         want, _ = key.o.gate_batch(key.p, key.bsk, key.ksk, "NAND", np.ascontiguousarray(a_h[sample]), np.ascontiguousarray(b_h[sample]))
         bit_ok = bool(np.array_equal(got[sample], want))
     else:
-        bit_ok = True                                    # ranks > 0 hold no host key: decrypt check only
+        bit_ok = None                                    # ranks > 0 hold no host key: decrypt check only, reported as such
     ctx.sync()
-    verified = dec_ok and bit_ok
+    verified = dec_ok and bit_ok is not False
+    per_rank = None
     if dist:
-        tt = torch.tensor([elapsed, 0.0 if verified else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, verified = float(tt[0].item()), float(tt[1].item()) == 0.0
+        tt = torch.tensor([elapsed, 0.0 if verified else 1.0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)        # host values over the gloo default group
+        elapsed_max = float(tt[0].item())
+        mine = {"rank": rank, "device": local_rank, "elapsed_s": elapsed, "verified": bool(verified),
+                "decrypts_ok": dec_ok, "oracle_bits_ok": bit_ok,
+                "blind_rotate_avg_ms": br_ms / max(br_n, 1), "keyswitch_avg_ms": ks_ms / max(ks_n, 1), "telemetry": sampler.summary()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        elapsed, verified = elapsed_max, float(tt[1].item()) == 0.0
+    ranks_verified = sum(1 for r in per_rank if r["verified"]) if per_rank else int(verified)
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * BATCH * args.steps / elapsed
@@ -513,13 +645,17 @@ def main():
             "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (real encryptions of random bits under a seeded cloud key; no external dataset)", "verified": verified,
+            "world_size": dist.get_world_size() if dist else 1, "ranks_verified": ranks_verified,
             "config": {"workload": "BASELINE configs[1]: batch of 1024 independent NAND bootstraps per GPU, "
                                    "128-bit params (n=700, N=1024, L=3, Bgbit=6, t=9), keys+inputs resident in HBM",
                        "batch_per_gpu": BATCH, "parallelism": f"batch-shard x{world} (replicated cloud key)", "collective_backend": backend if dist else None,
+                       "control_backend": "gloo" if dist else None,
                        "inputs": "real encryptions of random bits under a seeded key (harness PRNG)"},
             "roofline": {"kernel": "k_blind_rotate", "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source(),
                          "flops_per_launch": fp64_flops_per_bootstrap(p) * BATCH,
+                         "flops_note": "SURVEY 8d's radix-2 operation count (1,824 flop per lane and CMUX step); the radix-8 kernel executes 1,686, so "
+                                       "`achieved` overstates executed flops by 8 % (the usual convention: algorithmic work over time)",
                          "avg_launch_ms": br_avg_ms, "launches": br_n,
                          "hbm_streaming": {"algorithmic_bytes_per_launch": alg, "algorithmic_GBps": stream_gbs,
                                            "x_hbm_peak": stream_gbs / HBM_PEAK_GBS, "hbm_peak_GBps": HBM_PEAK_GBS,
@@ -537,7 +673,13 @@ def main():
                         "keyswitch_kernels": "k_ks_init + k_ks_onehot + k_keyswitch_mfma (exact int8 matrix-core product, csrc/keyswitch_mfma.hpp)",
                         "keyswitch_int8_Tops": 2.0 * BATCH * 4 * (p.n + 1) * (p.N * p.t * 4) / (ks_avg_ms * 1e-3) / 1e12 if ks_n else None,
                         "keyswitch_algorithmic_GBps": ks_alg / (ks_avg_ms * 1e-3) / 1e9 if ks_n else None},
+            "telemetry": {"what": "shader clock (MHz) and socket power (W) of each rank's GPU read through librocm_smi64 every 5 ms DURING the timed loop "
+                                  "(go-tfhe_amd/telemetry.py): the blind rotate runs power-limited, so a sub-linear multi-GPU figure can be "
+                                  "attributed to clocks here rather than guessed",
+                          "rank0": sampler.summary()},
         }
+        if per_rank:
+            line["per_rank"] = per_rank
         if key_broadcast_ms is not None:
             line["key_broadcast_ms"] = key_broadcast_ms
             line["key_distribution"] = ("rank 0 generates the cloud key on the host and uploads it; the other ranks receive the two device-layout "
@@ -557,16 +699,16 @@ def main():
                     f"fp64 Tflop/s if the kernel's {BR_VALU_PER_WAVE_STEP} VALU instructions per wave and CMUX step issued at the rate "
                     f"tools/ubench_ceilings measured on this box for {BR_WAVES_PER_SIMD} resident waves per SIMD ({ns:.3f} ns per instruction per SIMD; "
                     "the nominal peak assumes one every 4 cycles and 2 flop per lane, an FFT's mix is 1.42); the microbenchmark is short, "
-                    "the blind rotate itself runs power-limited -- ~1.36 kW of the board's 1.4 kW, shader clock ~2.26 GHz instead of 2.4 "
-                    "(profiles/r03_p_clock_power.txt) -- so the ceiling at the clock the kernel gets is ~6 % lower than this figure")
+                    "the blind rotate itself runs power-limited -- see `telemetry` for the clock and power of this run -- so the ceiling at "
+                    "the clock the kernel gets is a few per cent lower than this figure")
                 # the kernel's other pipe: DS instructions per wave and CMUX step (by kind; from the source and SQ_INSTS_LDS of the
                 # committed PMC pass) x their measured cost on this box x the eight resident waves of a CU, over the step's time
                 ld = ceil["lds_ns_per_wave_instr_per_cu"]
-                per_wave_ns = (BR_DS_PER_WAVE_STEP["ds_write_b128"] * ld["ds_write_b128"] + BR_DS_PER_WAVE_STEP["ds_read_b128"] * ld["ds_read_b128"]
-                               + BR_DS_PER_WAVE_STEP["ds_read_b32"] * ld["ds_read_b32"] + BR_DS_PER_WAVE_STEP["ds_add_u32"] * ld["ds_add_u32"])
+                per_wave_ns = sum(BR_DS_PER_WAVE_STEP[k] * ds_cost_ns(k, ld) for k in BR_DS_PER_WAVE_STEP)
                 step_ns = br_avg_ms * 1e6 / p.n
                 line["roofline"]["lds_pipe"] = {
-                    "ds_instructions_per_wave_step": BR_DS_PER_WAVE_STEP, "measured_ns_per_wave_instruction_per_cu": ld,
+                    "ds_instructions_per_wave_step": BR_DS_PER_WAVE_STEP, "ds_instructions_total": sum(BR_DS_PER_WAVE_STEP.values()),
+                    "measured_ns_per_wave_instruction_per_cu": ld, "priced_as": {k: f"{m:g} x {b}" for k, (b, m) in BR_DS_PRICED_AS.items()},
                     "busy_frac": 4 * BR_WAVES_PER_SIMD * per_wave_ns / step_ns,
                     "store_share": BR_DS_PER_WAVE_STEP["ds_write_b128"] * ld["ds_write_b128"] / per_wave_ns,
                     "note": "fraction of a CMUX step the CU's LDS pipe is busy with the kernel's DS instructions at their measured throughput "
@@ -575,108 +717,213 @@ def main():
                 line["roofline"]["hbm_streaming"]["x_measured_copy"] = stream_gbs / ceil["hbm_copy"]["kernel_copy_GBps"]
             except Exception:
                 pass
-            line["configs"] = extra_configs(pkg, key, ck, dev)
+            line["configs"] = extra_configs(pkg, key, ck, dev, ceil)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(key, a_h, b_h)
+
+    # ---- N > 1: the two BASELINE configs that are DEFINED as multi-GPU workloads, in the form the north star names (the batch
+    # starts on ONE rank: scatter -> local path -> gather, all timed), after the weak-scaling headline, on every rank
+    if world > 1 and not args.no_configs:
+        del a, b, out
+        cfg = {}
+        for name, fn in (("config5_mixed_stream_1M_sharded", lambda: sharded_mixed(pkg, p, key, ck, env, args.config5_gates, 1, 1)),
+                         ("config3_adder8_x256_sharded", lambda: sharded_adder(pkg, p, key, ck, env, 5, 2))):
+            try:
+                rec = fn()
+            except Exception as e:                        # noqa: BLE001 -- every rank must still reach the next collective
+                rec = {"error": f"{type(e).__name__}: {e}", "verified": False}
+            if rank == 0:
+                cfg[name] = rec
+        if rank == 0:
+            line["configs"] = cfg
     ck.close()
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         emit(line)
 
 
-def sharded_mode(args, pkg, p, key, ck, dist, backend, rank, world, dev):
-    """Root holds the batch; scatter -> local path -> gather is the timed region."""
-    import torch
-    from go_tfhe_amd.distributed import ShardedGates, ShardedCircuits, gpu_compute
-    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor, balance_levels, count_gates
-    n1 = p.n + 1
-    cdev = dev if backend == "nccl" else "cpu"              # gloo moves host tensors: stage through the host in dry runs
-    rs = np.random.RandomState(KEY_SEED)
+class DistEnv:
+    """What the sharded workloads need to know about the process group: `group` is the RCCL data group (None = the gloo
+    default group, host tensors), `cdev` the device collective tensors live on."""
 
-    def to_c(t):
-        return t if backend == "nccl" else t.cpu()
+    def __init__(self, dist, group, backend, rank, world, dev, local_rank):
+        self.dist, self.group, self.backend, self.rank, self.world, self.dev, self.local_rank = dist, group, backend, rank, world, dev, local_rank
+        self.cdev = dev if backend == "nccl" else "cpu"       # gloo moves host tensors: stage through the host (dry runs, RCCL fallback)
 
-    def local(fn):
-        if backend == "nccl":
+    def to_c(self, t):
+        return t if self.backend == "nccl" else t.cpu()
+
+    def local(self, fn):
+        """The local compute callable, staged through the device when the collectives move host tensors."""
+        if self.backend == "nccl":
             return fn
-        return lambda *xs: fn(*[x.to(dev) if hasattr(x, "to") else x for x in xs]).cpu()
+        return lambda *xs: fn(*[x.to(self.dev) if hasattr(x, "to") else x for x in xs]).cpu()
 
-    phases, checks = [], {}
-    if args.workload == "mixed":
-        total = args.gates or 131072 * world
-        eng = ShardedGates(local(gpu_compute(ck.ctx)), n1, device=cdev)
-        if rank == 0:
-            pool_bits = rs.randint(0, 2, 256)
-            pool = torch.from_numpy(key.enc(pool_bits, 77).view(np.int32)).to(dev)
-            ia, ib, ic = (torch.from_numpy(rs.randint(0, 256, total)).to(dev) for _ in range(3))
-            names = np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, total)]       # AND, OR, XOR, MUX
-            ops = torch.from_numpy(names).to(dev)
-            a, b, c = to_c(pool[ia]), to_c(pool[ib]), to_c(pool[ic])
-            ops_c = to_c(ops)
-            run = lambda: eng.gate_batch(ops_c, a, b, c)
-        else:
-            run = lambda: eng.gate_batch(None, None, None, None)
-        units, unit_name = total, "gates"
-    else:
-        C, bits = 256, 8
-        levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
-        ex = CircuitExecutor(ck.ctx, balance_levels(levels, max(1, 1024 // max(1, C // world))), n_wires)
-        eng = ShardedCircuits(local(ex.run), n_wires, n1, device=cdev)
-        in_wires = list(range(2 * bits)) + [adder_constant_wire(bits)]
-        out_wires = sums + [cout]
-        if rank == 0:
-            av, bv = rs.randint(0, 256, C), rs.randint(0, 256, C)
-            inp = np.zeros((len(in_wires), C, n1), np.uint32)
-            for i in range(bits):
-                inp[i] = key.enc((av >> i) & 1, 200 + i)
-                inp[bits + i] = key.enc((bv >> i) & 1, 300 + i)
-            inp[2 * bits] = pkg.gates.Constant(False, key.p)
-            inp_t = to_c(torch.from_numpy(inp.view(np.int32)).to(dev))
-            run = lambda: eng.run(in_wires, out_wires, inp_t)
-        else:
-            run = lambda: eng.run(in_wires, out_wires)
-        units, unit_name = count_gates(levels) * C, "gates"
+
+def _sharded_timed(env, eng, run, steps, warmup):
+    """warmup + `steps` timed runs of a root-held workload between barriers; returns (last result on root, record of the
+    max-over-ranks times, per-rank telemetry gathered on every rank)."""
+    import torch
+    from go_tfhe_amd import telemetry
+    dist = env.dist
     res = None
-    for _ in range(max(1, args.warmup)):
+    for _ in range(warmup):
         res = run()
+    phases = []
+    sampler = telemetry.Sampler(env.local_rank, period_s=0.01)
+    torch.cuda.synchronize()
     dist.barrier()
+    with sampler:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = run()
+            phases.append(dict(eng.last_timing))
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+    mine = [elapsed] + [sum(ph[k] for ph in phases) for k in ("scatter_s", "compute_s", "gather_s")]
+    tt = torch.tensor(mine, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    per_rank = [None] * env.world
+    dist.all_gather_object(per_rank, {"rank": env.rank, "elapsed_s": elapsed, "scatter_ms": mine[1] * 1e3 / steps,
+                                      "compute_ms": mine[2] * 1e3 / steps, "gather_ms": mine[3] * 1e3 / steps,
+                                      "telemetry": sampler.summary()})
+    tot = float(tt[0])
+    rec = {"n_gpus": env.world, "backend": env.backend, "steps": steps, "warmup": warmup, "seconds": tot / steps,
+           "ms_per_step": tot * 1e3 / steps, "scatter_ms_per_step": float(tt[1]) * 1e3 / steps,
+           "compute_ms_per_step": float(tt[2]) * 1e3 / steps, "gather_ms_per_step": float(tt[3]) * 1e3 / steps,
+           "times": "max over ranks; scatter includes root's packing of the batch into per-rank planes", "per_rank": per_rank}
+    return res, rec
+
+
+def sharded_mixed(pkg, p, key, ck, env, total, steps, warmup):
+    """BASELINE configs[4]: `total` mixed AND/OR/XOR/MUX gates held by rank 0 (gates.go:107-114 for MUX): one packed scatter,
+    every rank's contiguous shard through tfhe_gate_batch_dev, one gather -- all inside the timed region.  Returns the record
+    on rank 0 (None elsewhere).  Verified after the timed region: sampled outputs decrypt to the gate of their inputs and one
+    gate of each kind is bit-identical to the oracle."""
+    import torch
+    from go_tfhe_amd.distributed import ShardedGates, gpu_compute
+    dev, rank = env.dev, env.rank
+    n1 = p.n + 1
+    rs = np.random.RandomState(KEY_SEED + 5)
+    eng = ShardedGates(env.local(gpu_compute(ck.ctx)), n1, group=env.group, device=env.cdev)
+    ck.ctx.reserve(-(-total // env.world), with_mux=True)
+    if rank == 0:
+        pool_bits = rs.randint(0, 2, 256)
+        pool_h = key.enc(pool_bits, 77)
+        pool = torch.from_numpy(pool_h.view(np.int32)).to(dev)
+        ia_h, ib_h, ic_h = (rs.randint(0, 256, total) for _ in range(3))
+        names = np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, total)]       # AND, OR, XOR, MUX
+        ops_c = env.to_c(torch.from_numpy(names).to(dev))
+        a, b, c = (env.to_c(pool[torch.from_numpy(ix).to(dev)]) for ix in (ia_h, ib_h, ic_h))
+        run = lambda: eng.gate_batch(ops_c, a, b, c)
+    else:
+        run = lambda: eng.gate_batch(None, None, None, None)
+    res, rec = _sharded_timed(env, eng, run, steps, warmup)
+    if rank != 0:
+        return None
+    r = res.cpu().numpy().view(np.uint32)
+    A, Bb, Cc = (pool_bits[ix].astype(bool) for ix in (ia_h, ib_h, ic_h))
+    want = np.where(names == 1, A & Bb, np.where(names == 2, A | Bb, np.where(names == 3, A ^ Bb, np.where(A, Bb, Cc))))
+    sel = np.arange(0, total, max(1, total // 4096))
+    dec_ok = bool(np.array_equal(key.dec(np.ascontiguousarray(r[sel])), want[sel]))
+    opname = {1: "AND", 2: "OR", 3: "XOR", 10: "MUX"}
+    bit_ok = True
+    # one gate of each kind from the LAST rank's shard (it crossed the scatter and the gather) on the oracle
+    lo_last = (total * (env.world - 1)) // env.world
+    for code in (1, 2, 3, 10):
+        g = lo_last + int(np.argmax(names[lo_last:] == code))
+        w = key.o.gate(key.p, key.bsk, key.ksk, opname[code], np.ascontiguousarray(pool_h[ia_h[g]]), np.ascontiguousarray(pool_h[ib_h[g]]),
+                       np.ascontiguousarray(pool_h[ic_h[g]]) if code == 10 else None)
+        bit_ok &= bool(np.array_equal(r[g], w))
+    nb = int((names == 10).sum()) * 3 + int((names != 10).sum())
+    rec.update({"workload": f"BASELINE configs[4]: {total:,} mixed AND/OR/XOR/MUX gates held by rank 0, 128-bit params; contiguous shards over "
+                            f"{env.world} GPU(s), MUX = 3 bootstraps (gates.go:107-114) split on the device; scatter + compute + gather timed",
+                "gates": total, "bootstraps": nb, "rate": total / rec["seconds"], "unit": "gates/s", "bootstraps_per_s": nb / rec["seconds"],
+                "bytes_scattered": int(3 * total * n1 * 4 + total * 4), "bytes_gathered": int(total * n1 * 4),
+                "verified": dec_ok and bit_ok,
+                "checks": {f"{len(sel)}_sampled_outputs_decrypt_correctly": dec_ok,
+                           "one_gate_of_each_kind_from_the_last_ranks_shard_bit_identical_to_oracle": bit_ok}})
+    return rec
+
+
+def small_launch_floor_ms(ck, key, dev, reps=5):
+    """One gate through tfhe_gate_batch_dev (blind rotate of 700 sequential CMUX steps + key switch): the latency floor of
+    every circuit level of at most one bootstrap per CU, measured on this rank."""
+    import torch
+    x = torch.from_numpy(key.enc(np.array([1]), 4242).view(np.int32)).to(dev)
+    y = torch.empty_like(x)
+    for _ in range(2):
+        ck.ctx.gate_batch_dev("NAND", x, x, None, y, torch.cuda.current_stream())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = run()
-        phases.append(dict(eng.last_timing))
+    for _ in range(reps):
+        ck.ctx.gate_batch_dev("NAND", x, x, None, y, torch.cuda.current_stream())
     torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    tt = torch.tensor([elapsed] + [sum(ph[k] for ph in phases) for k in ("scatter_s", "compute_s", "gather_s")], dtype=torch.float64)
-    if backend == "nccl":
-        tt = tt.to(dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return (time.perf_counter() - t0) * 1e3 / reps
+
+
+def sharded_adder(pkg, p, key, ck, env, steps, warmup):
+    """BASELINE configs[2]: the reference's 8-bit ripple-carry adder (README.md:78-106: 40 gates, 17 levels) x 256 circuits held by
+    rank 0, sharded BY CIRCUIT (carries never leave their GPU): scatter of the input wires, the whole levelised circuit on each
+    rank's share, gather of the nine output wires -- all timed.  Verified: every sum and carry decrypts to a + b; the nine output
+    wires of one circuit of the LAST rank's share are bit-identical to the oracle's gate-by-gate run."""
+    import torch
+    from go_tfhe_amd.distributed import ShardedCircuits, shard_sizes, shard_bounds
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor, schedule_min_cost, count_gates
+    dev, rank, world = env.dev, env.rank, env.world
+    n1 = p.n + 1
+    C, bits = 256, 8
+    rs = np.random.RandomState(KEY_SEED + 3)
+    levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+    share = max(shard_sizes(C, world))
+    sched = schedule_min_cost(levels, share)
+    ex = CircuitExecutor(ck.ctx, sched, n_wires)
+    eng = ShardedCircuits(env.local(ex.run), n_wires, n1, group=env.group, device=env.cdev)
+    in_wires = list(range(2 * bits)) + [adder_constant_wire(bits)]
+    out_wires = sums + [cout]
     if rank == 0:
-        r = res.cpu().numpy().view(np.uint32) if backend == "nccl" else res.numpy().view(np.uint32)
-        if args.workload == "mixed":
-            A, Bb, Cc = (pool_bits[x.cpu().numpy()].astype(bool) for x in (ia, ib, ic))
-            want = np.where(names == 1, A & Bb, np.where(names == 2, A | Bb, np.where(names == 3, A ^ Bb, np.where(A, Bb, Cc))))
-            sel = np.arange(0, total, max(1, total // 4096))
-            checks["sampled_decrypts_correct"] = bool(np.array_equal(key.dec(np.ascontiguousarray(r[sel])), want[sel]))
-            nb = int((names == 10).sum()) * 3 + int((names != 10).sum())
-            extra = {"bootstraps": nb, "bootstraps_per_s": nb * args.steps / float(tt[0])}
-        else:
-            got = sum(key.dec(np.ascontiguousarray(r[i])).astype(np.int64) << i for i in range(8)) + (key.dec(np.ascontiguousarray(r[8])).astype(np.int64) << 8)
-            checks["all_sums_correct"] = bool(np.array_equal(got, av + bv))
-            extra = {"circuits": 256, "additions_per_s": 256 * args.steps / float(tt[0])}
-        line = {"metric": "gate bootstraps/sec, batch held by rank 0 (scatter + compute + gather timed)", "mode": "sharded",
-                "workload": {"mixed": "BASELINE config 5: mixed AND/OR/XOR/MUX stream", "adder": "BASELINE config 3: 8-bit ripple-carry adder (40 gates) x 256 circuits, sharded by circuit"}[args.workload],
-                "value": units * args.steps / float(tt[0]), "unit": f"{unit_name}/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": float(tt[0]) * 1e3 / args.steps, "backend": backend,
-                "scatter_ms_per_step": float(tt[1]) * 1e3 / args.steps, "compute_ms_per_step": float(tt[2]) * 1e3 / args.steps,
-                "gather_ms_per_step": float(tt[3]) * 1e3 / args.steps, "scaling": "strong", "verified": all(checks.values()),
-                "checks": checks, **extra}
-    ck.close()
-    dist.destroy_process_group()
-    if rank == 0:
-        emit(line)
+        av, bv = rs.randint(0, 256, C), rs.randint(0, 256, C)
+        inp = np.zeros((len(in_wires), C, n1), np.uint32)
+        for i in range(bits):
+            inp[i] = key.enc((av >> i) & 1, 200 + i)
+            inp[bits + i] = key.enc((bv >> i) & 1, 300 + i)
+        inp[2 * bits] = pkg.gates.Constant(False, key.p)
+        inp_t = env.to_c(torch.from_numpy(inp.view(np.int32)).to(dev))
+        run = lambda: eng.run(in_wires, out_wires, inp_t)
+    else:
+        run = lambda: eng.run(in_wires, out_wires)
+    res, rec = _sharded_timed(env, eng, run, steps, warmup)
+    floor = small_launch_floor_ms(ck, key, dev)
+    fl = torch.tensor([floor], dtype=torch.float64)
+    env.dist.all_reduce(fl, op=env.dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    r = res.cpu().numpy().view(np.uint32)
+    got = sum(key.dec(np.ascontiguousarray(r[i])).astype(np.int64) << i for i in range(bits)) + (key.dec(np.ascontiguousarray(r[bits])).astype(np.int64) << bits)
+    sums_ok = bool(np.array_equal(got, av + bv))
+    c0 = shard_bounds(C, world, world - 1)[0] + 1                 # a circuit of the last rank's share, gate by gate on the oracle
+    ow = {w: inp[k, c0] for k, w in enumerate(in_wires)}
+    for lvl in levels:
+        for (op, x, y, z, w_out) in lvl:
+            ow[w_out] = key.o.gate(key.p, key.bsk, key.ksk, op, np.ascontiguousarray(ow[x]), np.ascontiguousarray(ow[y]))
+    wires_ok = all(bool(np.array_equal(r[k, c0], ow[w])) for k, w in enumerate(out_wires))
+    G = count_gates(levels) * C
+    widths = [len(l) * share for l in sched]
+    rec.update({"workload": f"BASELINE configs[2]: 8-bit ripple-carry adder as the reference writes it (40 gates, 17 levels) x 256 circuits held by rank 0, "
+                            f"128-bit params, sharded by circuit over {world} GPU(s) ({share} circuits per GPU); scatter + levelised circuit + gather timed",
+                "gates": G, "circuits": C, "rate": G / rec["seconds"], "unit": "gates/s", "additions_per_s": C / rec["seconds"],
+                "levels": len(sched), "level_widths_per_gpu": widths,
+                "latency_bound": {"one_gate_launch_ms": float(fl[0]), "levels": len(sched), "bound_ms": len(sched) * float(fl[0]),
+                                  "note": "every level is one launch of 700 sequential CMUX steps + key switch whatever its width up to one bootstrap per CU: "
+                                          "with the circuits spread over more GPUs the levels get narrower, not fewer, so this workload's multi-GPU time "
+                                          "approaches levels x the one-gate launch time (measured on the slowest rank) -- a latency bound, not a communication cost"},
+                "verified": sums_ok and wires_ok,
+                "checks": {"all_256_sums_and_carries_decrypt_to_a_plus_b": sums_ok,
+                           "output_wires_of_one_circuit_of_the_last_ranks_share_bit_identical_to_oracle": wires_ok}})
+    return rec
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for the two path kernels (run ON the GPU box, from the repo root):
-#   tools/prof_pmc.sh <tag> [batch] [params]      (params given: tools/pmc_workload.py at that set, SQ passes only)
+#   tools/prof_pmc.sh <tag> [batch] [params]      (params given: tools/pmc_workload.py at that set)
 # Each pass is its own rocprofv3 run with --kernel-trace only (no other trace domains).
 set -u
 TAG=${1:-pmc}; B=${2:-1024}; PSET=${3:-}
@@ -18,10 +18,8 @@ run() { # name counters...
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM
-if [ -z "$PSET" ]; then
 run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
-fi
 python3 $R/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
