@@ -755,6 +755,12 @@ class DistEnv:
     def to_c(self, t):
         return t if self.backend == "nccl" else t.cpu()
 
+    def sync(self):
+        """Wait for this rank's GPU (a no-op in the CPU tier's gloo tests of this plumbing, where dev is the host)."""
+        import torch
+        if torch.device(self.dev).type == "cuda":
+            torch.cuda.synchronize()
+
     def local(self, fn):
         """The local compute callable, staged through the device when the collectives move host tensors."""
         if self.backend == "nccl":
@@ -773,14 +779,14 @@ def _sharded_timed(env, eng, run, steps, warmup):
         res = run()
     phases = []
     sampler = telemetry.Sampler(env.local_rank, period_s=0.01)
-    torch.cuda.synchronize()
+    env.sync()
     dist.barrier()
     with sampler:
         t0 = time.perf_counter()
         for _ in range(steps):
             res = run()
             phases.append(dict(eng.last_timing))
-        torch.cuda.synchronize()
+        env.sync()
         dist.barrier()
         elapsed = time.perf_counter() - t0
     mine = [elapsed] + [sum(ph[k] for ph in phases) for k in ("scatter_s", "compute_s", "gather_s")]

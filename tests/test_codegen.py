@@ -42,6 +42,30 @@ EXPECT = {
 }
 
 
+def step_loop_mix(body):
+    """Static instruction mix of the kernel's CMUX step loop: the innermost-numbered backward branch region that contains an
+    s_barrier and the most instructions.  Returns {"valu": n, "ds": {opcode: n}, "barriers": n} (None when no such loop)."""
+    lines = body.splitlines()
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+    best = None
+    for i, l in enumerate(lines):
+        m = re.match(r"^\s*s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if not m or labels.get(m.group(1), len(lines)) >= i:
+            continue
+        ops = [x.split()[0] for x in lines[labels[m.group(1)]:i + 1] if re.match(r"^\s+[a-z]", x)]
+        if "s_barrier" not in ops:
+            continue
+        if best is None or len(ops) > len(best):
+            best = ops
+    if best is None:
+        return None
+    ds = {}
+    for x in best:
+        if x.startswith("ds_"):
+            ds[x] = ds.get(x, 0) + 1
+    return {"valu": sum(1 for x in best if x.startswith("v_")), "ds": ds, "barriers": best.count("s_barrier")}
+
+
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
@@ -62,6 +86,7 @@ def asm(tmp_path_factory):
         meta = meta[: meta.index(".end_amdhsa_kernel")]
         key = re.sub(r"^void tfhe::|\(tfhe::BlindRotateArgs\)$", "", pretty)
         kernels[key] = {
+            "loop": step_loop_mix(body),
             "s_load": len(re.findall(r"^\s*s_load_dwordx", body, re.M)),
             "v_load": len(re.findall(r"^\s*global_load_dwordx4", body, re.M)),
             "vgpr": int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta).group(1)),
@@ -79,3 +104,37 @@ def test_uniform_twiddle_loads_are_scalar_and_budgets_hold(asm, kernel):
     assert k["s_load"] >= min_s, f"{kernel}: only {k['s_load']} scalar loads (expected >= {min_s})"
     assert k["vgpr"] <= max_vgpr, f"{kernel}: {k['vgpr']} VGPRs"
     assert k["scratch"] <= max_scratch, f"{kernel}: {k['scratch']} bytes of scratch (spills)"
+
+
+def test_bench_constants_equal_the_compiled_step_loop(asm):
+    """bench.py's `roofline.attainable` and `lds_pipe` are computed from the headline kernel's instruction counts per wave and
+    CMUX step.  They are constants in bench.py -- and this test holds them to the compiled kernel: the static VALU count of
+    the step loop (+-2: an instruction moved across the loop boundary is not a change of the kernel's cost) and every DS opcode
+    count exactly.  (The static counts equal the PMC counters of the committed rocprofv3 pass -- SQ_INSTS_VALU 2.1437e9 /
+    2,048 waves / 700 steps = 1,495, SQ_INSTS_LDS 2.667e8 -> 186 -- because the step loop is one straight-line block.)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.BR_KERNEL in asm, f"{bench.BR_KERNEL} is not instantiated any more"
+    mix = asm[bench.BR_KERNEL]["loop"]
+    assert mix is not None and mix["barriers"] == 1, mix
+    assert abs(mix["valu"] - bench.BR_VALU_PER_WAVE_STEP) <= 2, \
+        f"step loop of {bench.BR_KERNEL} has {mix['valu']} VALU instructions, bench.BR_VALU_PER_WAVE_STEP says {bench.BR_VALU_PER_WAVE_STEP}"
+    assert mix["ds"] == bench.BR_DS_PER_WAVE_STEP, f"DS instructions of the step loop {mix['ds']} != bench.BR_DS_PER_WAVE_STEP {bench.BR_DS_PER_WAVE_STEP}"
+    for kind in bench.BR_DS_PER_WAVE_STEP:                     # every kind has a price in the LDS-pipe model
+        base, _ = bench.BR_DS_PRICED_AS.get(kind, (kind, 1.0))
+        assert base in ("ds_write_b128", "ds_read_b128", "ds_read_b32", "ds_add_u32"), kind
+
+
+def test_traffic_source_names_the_committed_measurement():
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    src = bench.traffic_source()
+    assert src["file"] == "profiles/pmc_traffic.json" and os.path.exists(os.path.join(ROOT, src["file"]))
+    assert src["collected"] and "source_commit" in src["collected"]
+    for f in ("pmc_traffic.json", "pmc_traffic_uint5.json"):
+        rec = json.load(open(os.path.join(ROOT, "profiles", f)))
+        for k in ("k_blind_rotate", "k_keyswitch"):
+            assert rec[k]["hbm_bytes_per_launch"] == pytest.approx((2 * rec[k]["FETCH_SIZE_KiB"] + rec[k]["WRITE_SIZE_KiB"]) * 1024)

@@ -115,3 +115,57 @@ def test_sharded_gates_world2_gloo(built):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's multi-rank plumbing without a GPU: the backend handshake must put EVERY rank on gloo when RCCL cannot
+    form a group (no device here), and the timed sharded loop (barriers, max-over-ranks reduce, per-rank records with
+    telemetry that degrades to 'unavailable') must run over it with a ShardedGates engine."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import bench
+    graft = bench.graft
+    graft.load_package()
+    from go_tfhe_amd.distributed import ShardedGates
+    dist, group, backend = bench.init_distributed(rank, world, torch.device("cpu"), "nccl")
+    ok = backend == "gloo" and group is None and dist.get_world_size() == world
+    env = bench.DistEnv(dist, group, backend, rank, world, torch.device("cpu"), 0)
+    ok = ok and env.cdev == "cpu"
+    n1 = 9
+
+    def compute(ops, a, b, c):                                  # stand-in for the local path: out = a + b (mod 2^32)
+        return a + b
+
+    eng = ShardedGates(compute, n1)
+    B = 5
+    if rank == 0:
+        a = torch.arange(B * n1, dtype=torch.int32).view(B, n1)
+        b = torch.ones((B, n1), dtype=torch.int32)
+        run = lambda: eng.gate_batch("NAND", a, b)
+    else:
+        run = lambda: eng.gate_batch(None, None, None, None)
+    res, rec = bench._sharded_timed(env, eng, run, steps=3, warmup=1)
+    if rank == 0:
+        ok = ok and torch.equal(res, a + b)
+        ok = ok and rec["n_gpus"] == world and rec["steps"] == 3 and len(rec["per_rank"]) == world
+        ok = ok and [r["rank"] for r in rec["per_rank"]] == list(range(world))
+        ok = ok and all(r["telemetry"]["available"] is False for r in rec["per_rank"])       # no SMI device in this tier
+        ok = ok and rec["ms_per_step"] >= max(rec["scatter_ms_per_step"], rec["compute_ms_per_step"], rec["gather_ms_per_step"]) > 0
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_backend_handshake_and_sharded_loop_world2_gloo(built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
