@@ -84,6 +84,21 @@ template <int S> __device__ __forceinline__ void dft4(cd (&x)[4])
     x[0] = t0 + t2; x[2] = t0 - t2; x[1] = t1 + t3; x[3] = t1 - t3;
 }
 
+// Pre-twist by (1, w1, w2, w3), then dft4<S>: a forward level.  The products x2*w2 and x3*w3 are never formed: they go
+// straight into the first butterfly stage as FMA chains (t0 = x0 + x2 w2: four FMAs) and the difference is recovered as
+// 2 x0 - t0 (two FMAs) -- 24 instructions instead of the 12 + 16 of three cmul and a dft4.  The recovered difference
+// carries t0's rounding error (half an ulp of the larger of the two), i.e. the transform's error stays of the same order:
+// exactness margin at N = 1024, L = 3 is ~0.006 against 0.5, outputs are bit-identical.
+template <int S> __device__ __forceinline__ void dft4_pretwist(cd (&x)[4], const cd w1, const cd w2, const cd w3)
+{
+    const cd t0 = {fma(x[2].re, w2.re, fma(-x[2].im, w2.im, x[0].re)), fma(x[2].re, w2.im, fma(x[2].im, w2.re, x[0].im))};
+    const cd t1 = {fma(2.0, x[0].re, -t0.re), fma(2.0, x[0].im, -t0.im)};
+    const cd y1 = cmul(x[1], w1);
+    const cd t2 = {fma(x[3].re, w3.re, fma(-x[3].im, w3.im, y1.re)), fma(x[3].re, w3.im, fma(x[3].im, w3.re, y1.im))};
+    const cd t3 = mul_i<S>(cd{fma(2.0, y1.re, -t2.re), fma(2.0, y1.im, -t2.im)});
+    x[0] = t0 + t2; x[2] = t0 - t2; x[1] = t1 + t3; x[3] = t1 - t3;
+}
+
 // LDS slots (16 B each, 256 per wave) of the three exchanges; (hi, mid, lo) = the lane's three base-4 digits.
 //   exchange 1: element (reg m; lane b,c,d)      at 64m + 16b + 4c + d
 //   exchange 2: element (reg m'; lane m,c,d)     at 64m + 16m' + 4((c+m')&3) + d
@@ -107,9 +122,7 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
 {
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-#pragma unroll
-        for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], T[a]);
-        dft4<1>(x[t]);
+        dft4_pretwist<1>(x[t], T[1], T[2], T[3]);
         #pragma unroll
         for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];
         wave_lds_order();
@@ -119,9 +132,7 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-#pragma unroll
-        for (int b = 1; b < 4; b++) x[t][b] = cmul(x[t][b], tw.w[0][b - 1]);
-        dft4<1>(x[t]);
+        dft4_pretwist<1>(x[t], tw.w[0][0], tw.w[0][1], tw.w[0][2]);
         #pragma unroll
         for (int mp = 0; mp < 4; mp++) sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo] = x[t][mp];
         wave_lds_order();
@@ -131,9 +142,7 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-#pragma unroll
-        for (int c = 1; c < 4; c++) x[t][c] = cmul(x[t][c], tw.w[1][c - 1]);
-        dft4<1>(x[t]);
+        dft4_pretwist<1>(x[t], tw.w[1][0], tw.w[1][1], tw.w[1][2]);
         #pragma unroll
         for (int mpp = 0; mpp < 4; mpp++) sc[64 * q.hi + 16 * q.lo + 4 * q.mid + ((q.lo + mpp) & 3)] = x[t][mpp];
         wave_lds_order();
@@ -143,9 +152,7 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-#pragma unroll
-        for (int d = 1; d < 4; d++) x[t][d] = cmul(x[t][d], tw.w[2][d - 1]);
-        dft4<1>(x[t]);
+        dft4_pretwist<1>(x[t], tw.w[2][0], tw.w[2][1], tw.w[2][2]);
     }
 }
 
@@ -179,14 +186,8 @@ __device__ __forceinline__ void fft256_forward_batch_pipe(cd (&x)[NB][4], cd *sc
         wave_lds_order();
     };
     auto level = [&](int lvl, int t) {
-        if (lvl == 1) {
-#pragma unroll
-            for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], T[a]);
-        } else {
-#pragma unroll
-            for (int a = 1; a < 4; a++) x[t][a] = cmul(x[t][a], tw.w[lvl - 2][a - 1]);
-        }
-        dft4<1>(x[t]);
+        if (lvl == 1) dft4_pretwist<1>(x[t], T[1], T[2], T[3]);
+        else dft4_pretwist<1>(x[t], tw.w[lvl - 2][0], tw.w[lvl - 2][1], tw.w[lvl - 2][2]);
     };
     auto mix = [&]() {
 #pragma unroll
@@ -437,27 +438,24 @@ __global__ __launch_bounds__(256 * ITEMS, WPS) void k_blind_rotate_quad(BlindRot
 // is one signed table of 3N words per polynomial, T[s] = acc[s], ~acc[s - N], acc[s - 2N], shared by the polynomial's
 // four waves: the decomposition reads X^a*acc - acc through two base addresses and immediate offsets, each wave
 // updates its quarter of the coefficients after the half swap, and a third barrier publishes the table.
-constexpr int kOctKeyGap = 8;        // VALU instructions between two key loads of a step's prologue
-template <int L, int BGBIT, int LB, int NL>
+template <int L, int BGBIT, int LB, int NL, int NK>
 __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint32_t *Tp /* signed table of polynomial p */,
-                                            int at, double sr, int lane, int p,
-                                            const cd *__restrict__ key_iph /* &bskq[i][p][h][0] */, cd *sc,
-                                            const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q, cd (&keep)[4],
+                                            int at, double sr, int lane, const QuadKeys (&K)[NK] /* this step's slices, levels LB.. */,
+                                            cd *sc, const cd *__restrict__ T, const QuadTwiddles &tw, const QuadLane q, cd (&keep)[4],
                                             cd (&send)[4], PhaseClock &tr)
 {
     constexpr int N = 1024;
-    QuadKeys K[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) load_quad_keys(K[l], key_iph + (size_t)(LB + l) * 512, p, lane);
     cd x[NL][4];
     // X^at * acc - acc straight from the signed table (T[s] = acc[s], ~acc[s - N], acc[s - 2N] for s in [0, N), [N, 2N),
     // [2N, 3N)): two base addresses per step, every coefficient an immediate offset from them
-    const uint32_t *rot = Tp + ((lane - at) & (2 * N - 1)), *own = Tp + lane;
+    // -acc[j] = ~acc[j] + 1 and ~acc[j] is the table's middle copy: rot - own + offset is ONE v_add3_u32
+    const uint32_t *rot = Tp + ((lane - at) & (2 * N - 1)), *own_c = Tp + N + lane;
+    const uint32_t off1 = A.offset + 1u;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         uint32_t dd[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) dd[k] = (rot[64 * a + 256 * k] - own[64 * a + 256 * k] + A.offset) ^ digit_flip_mask<L, BGBIT>();
+        for (int k = 0; k < 4; k++) dd[k] = (rot[64 * a + 256 * k] + own_c[64 * a + 256 * k] + off1) ^ digit_flip_mask<L, BGBIT>();
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             const int shift = 32 - (LB + l + 1) * BGBIT;
@@ -465,14 +463,6 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
             const int lo_im = digit_of<BGBIT>(dd[2], shift), hi_im = digit_of<BGBIT>(dd[3], shift);
             x[l][a] = cd{fma(sr, (double)(hi_re - hi_im), (double)lo_re), fma(sr, (double)(hi_re + hi_im), (double)lo_im)};
         }
-    }
-    // the gather first, then the key loads trickle out between the digit arithmetic: eight waves issuing 8 NL loads
-    // back to back queue behind each other at the CU's one address path and start the decomposition late
-    __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-#pragma unroll
-    for (int t = 0; t < 8 * NL; t++) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, kOctKeyGap, 0);
     }
     tr.mark(0);
     if constexpr (NL > 1) fft256_forward_batch_pipe<NL>(x, sc, T, tw, q);
@@ -491,6 +481,7 @@ __device__ __forceinline__ void oct_forward(const BlindRotateArgs &A, const uint
             }
         }
 }
+
 
 template <int L, int BGBIT>
 __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
@@ -548,11 +539,29 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
     const int nsteps = A.nsteps;
     PhaseClock tr;
     tr.start();
+    // The key slices of a step are requested in the IDLE part of the previous step -- group 1 right after its products (it
+    // then waits ~2,900 cycles for group 0 at barrier 1), group 0 right after barrier 1 (it waits for group 1's inverse) -- so
+    // the 8 or 16 loads per wave, their address arithmetic and their queueing at the CU's one address path are off the
+    // critical path, and a step starts with its decomposition.  K is one register set for both groups (a wave is in one).
+    QuadKeys K[L0];
+    const int LBg = g == 0 ? 0 : L0;
+    auto request_keys = [&](int step) {
+        const cd *kp = key + (size_t)step * kStep + (size_t)LBg * 512;
+        if (g == 0) {
+#pragma unroll
+            for (int l = 0; l < L0; l++) load_quad_keys(K[l], kp + (size_t)l * 512, p, lane);
+        } else {
+#pragma unroll
+            for (int l = 0; l < L1; l++) load_quad_keys(K[l], kp + (size_t)l * 512, p, lane);
+        }
+    };
+    if (nsteps > 0) request_keys(0);
     for (int i = 0; i < nsteps; i++) {
         const int at = __builtin_amdgcn_readfirstlane((int)abarL[i]);
+        const int inext = i + 1 < nsteps ? i + 1 : i;          // the last step re-requests its own slices (never used)
         cd keep[4], send[4];
         if (g == 0) {
-            oct_forward<L, BGBIT, 0, L0>(A, Tp, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
+            oct_forward<L, BGBIT, 0, L0>(A, Tp, at, sr, lane, K, sc, T, tw, q, keep, send, tr);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sc[k * 64 + lane] = keep[k];
@@ -560,9 +569,10 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
             }
             wave_lds_order();       // (*) see below
         } else {
-            oct_forward<L, BGBIT, L0, L1>(A, Tp, at, sr, lane, p, key + (size_t)i * kStep, sc, T, tw, q, keep, send, tr);
+            oct_forward<L, BGBIT, L0, L1>(A, Tp, at, sr, lane, K, sc, T, tw, q, keep, send, tr);
 #pragma unroll
             for (int k = 0; k < 4; k++) sendG[1][ph][k * 64 + lane] = send[k];
+            request_keys(inext);
             wave_lds_order();       // (*)
         }
         // (*) Every conditional block of this loop ENDS IN A FENCE (no instruction: wavefront scope).  LLVM marks a uniform
@@ -573,6 +583,10 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
         tr.mark(2);
         __syncthreads();
         tr.mark(3);
+        if (g == 0) {
+            request_keys(inext);
+            wave_lds_order();       // (*)
+        }
         if (g == 1) {
 #pragma unroll
             for (int k = 0; k < 4; k++)
