@@ -209,9 +209,10 @@ def measured_ceilings():
 # VALU instructions a wave of k_blind_rotate<3,6,2,FULL> (the full-launch form) issues per CMUX step and its occupancy: what
 # `roofline.attainable` is computed from.  A STATIC count of the compiled step loop, which tests/test_codegen.py re-derives from the
 # gfx950 assembly on every CPU-tier run (+-2) -- and equal to SQ_INSTS_VALU / waves / steps of the committed rocprofv3 PMC pass
-# (profiles/r03_p_pmc_summary.txt: 2.1437e9 / 2,048 / 700 = 1,495).  Changing the kernel without updating these fails the CPU tier.
+# (profiles/r04_c_pmc_summary.txt; round 3: 1,495, before the forward levels' twiddle products were folded into their first butterfly
+# stage).  Changing the kernel without updating these fails the CPU tier.
 BR_KERNEL = "k_blind_rotate<3, 6, 2, true>"
-BR_VALU_PER_WAVE_STEP = 1495
+BR_VALU_PER_WAVE_STEP = 1423
 BR_WAVES_PER_SIMD = 2
 # ... and its DS instructions per wave and step, by opcode as compiled (186 in all = SQ_INSTS_LDS / waves / steps): 4 transforms x 2
 # exchanges x 8 + 8 (product hand-over) 16-byte stores and as many loads; 32 accumulator words read as 18 ds_read_b32 + 7 paired

@@ -69,9 +69,7 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
     {
         const int hi = lane >> 3, lo = lane & 7;
         const cd *t0 = table, *t1 = table + kTwCount1024;
-#pragma unroll
-        for (int a = 1; a < 8; a++) { y0[a] = cmul(y0[a], t0[a]); y1[a] = cmul(y1[a], t1[a]); }
-        dft8<1>(y0);
+        dft8_pretwist<1>(y0, t0[1], t0[2], t0[3], t0[4], t0[5], t0[6], t0[7]);
         TFHE_PRIO(3);
 #pragma unroll
         for (int m = 0; m < 8; m++) sc[SL1W(m)] = y0[m];
@@ -80,7 +78,7 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
         for (int b = 0; b < 8; b++) y0[b] = sc[SL1R(b)];
         wave_lds_order();
         TFHE_PRIO(0);
-        dft8<1>(y1);
+        dft8_pretwist<1>(y1, t1[1], t1[2], t1[3], t1[4], t1[5], t1[6], t1[7]);
         TFHE_PRIO(3);
 #pragma unroll
         for (int m = 0; m < 8; m++) sc[SL1W(m)] = y1[m];
@@ -89,8 +87,7 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
         for (int b = 0; b < 8; b++) y1[b] = sc[SL1R(b)];
         wave_lds_order();
         TFHE_PRIO(0);
-        twist_pow<false>(y0, tw.h[0].l2);
-        dft8<1>(y0);
+        twist_pow_dft8(y0, tw.h[0].l2);
         TFHE_PRIO(3);
 #pragma unroll
         for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = y0[mp];
@@ -99,8 +96,7 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
         for (int c = 0; c < 8; c++) y0[c] = sc[SL2R(c)];
         wave_lds_order();
         TFHE_PRIO(0);
-        twist_pow<false>(y1, tw.h[1].l2);
-        dft8<1>(y1);
+        twist_pow_dft8(y1, tw.h[1].l2);
         TFHE_PRIO(3);
 #pragma unroll
         for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = y1[mp];
@@ -109,10 +105,8 @@ __device__ __forceinline__ void fft1024_forward(cd (&x)[16], cd *sc, const cd *_
         for (int c = 0; c < 8; c++) y1[c] = sc[SL2R(c)];
         wave_lds_order();
         TFHE_PRIO(0);
-        twist_pow<false>(y0, tw.h[0].l3);
-        dft8<1>(y0);
-        twist_pow<false>(y1, tw.h[1].l3);
-        dft8<1>(y1);
+        twist_pow_dft8(y0, tw.h[0].l3);
+        twist_pow_dft8(y1, tw.h[1].l3);
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) { x[k] = y0[k]; x[8 + k] = y1[k]; }

@@ -78,9 +78,7 @@ __device__ __forceinline__ void fft256_forward(cd (&x)[8], cd *sch, const cd *__
                                                const LaneTwiddles512 &tw, int hl)
 {
     const int hi = hl >> 2, lo = hl & 3;
-#pragma unroll
-    for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
-    dft8<1>(x);
+    dft8_pretwist<1>(x, table[1], table[2], table[3], table[4], table[5], table[6], table[7]);
     // exchange 1: (reg m, hl 4b+c) -> (reg b, hl 4m+c)
 #pragma unroll
     for (int m = 0; m < 8; m++) sch[36 * m + hl] = x[m];
@@ -88,8 +86,7 @@ __device__ __forceinline__ void fft256_forward(cd (&x)[8], cd *sch, const cd *__
 #pragma unroll
     for (int b = 0; b < 8; b++) x[b] = sch[36 * hi + 4 * b + lo];
     wave_lds_order();
-    twist_pow<false>(x, tw.l2);
-    dft8<1>(x);
+    twist_pow_dft8(x, tw.l2);
     // exchange 2: (reg m', hl 4m+c) -> (reg 4q+c, hl 4m+i), m' = 4q+i; slot 36m + 4m' + ((c+m')&3)
 #pragma unroll
     for (int mp = 0; mp < 8; mp++) sch[36 * hi + 4 * mp + ((lo + mp) & 3)] = x[mp];

@@ -47,11 +47,11 @@ template <int S> __device__ __forceinline__ cd mul_i(cd a) { return S > 0 ? cd{-
 // y_k = sum_n x_n exp(S * 2 pi i n k / 8), in place, natural order in and out.
 // 52 adds + 8 FMAs: the two 1/sqrt2 rotations of the odd half are not applied to d1, d3
 // themselves but folded into the FMAs that consume them (x1,x5 = f0 +- h*s, x3,x7 = f2 +- h*i*t).
-template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
+// dft8_finish: its second and third stage, from the first stage's sums b0..b3 and differences d0, t1, t2, t3.
+template <int S> __device__ __forceinline__ void dft8_finish(cd (&x)[8], const cd b0, const cd b1, const cd b2, const cd b3, const cd d0,
+                                                             const cd t1, const cd t2, const cd t3)
 {
     constexpr double h = 0.70710678118654752440;
-    cd b0 = x[0] + x[4], b1 = x[1] + x[5], b2 = x[2] + x[6], b3 = x[3] + x[7];
-    cd d0 = x[0] - x[4], t1 = x[1] - x[5], t2 = x[2] - x[6], t3 = x[3] - x[7];
     // u1 = t1 * (1 + S i), u3 = t3 * (-1 + S i)   (sqrt2 * the twiddled values)
     cd u1 = S > 0 ? cd{t1.re - t1.im, t1.im + t1.re} : cd{t1.re + t1.im, t1.im - t1.re};
     cd u3 = S > 0 ? cd{-t3.re - t3.im, t3.re - t3.im} : cd{t3.im - t3.re, -t3.im - t3.re};
@@ -64,6 +64,32 @@ template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
     x[5] = cd{fma(-h, s.re, f0.re), fma(-h, s.im, f0.im)};
     x[3] = cd{fma(h, t.re, f2.re), fma(h, t.im, f2.im)};
     x[7] = cd{fma(-h, t.re, f2.re), fma(-h, t.im, f2.im)};
+}
+template <int S> __device__ __forceinline__ void dft8(cd (&x)[8])
+{
+    dft8_finish<S>(x, x[0] + x[4], x[1] + x[5], x[2] + x[6], x[3] + x[7], x[0] - x[4], x[1] - x[5], x[2] - x[6], x[3] - x[7]);
+}
+
+// a + b*w as two FMA chains (the product b*w is never formed), and the matching difference a - b*w = 2a - (a + b*w)
+__device__ __forceinline__ cd cfma_to(cd a, cd b, cd w)
+{
+    return {fma(b.re, w.re, fma(-b.im, w.im, a.re)), fma(b.re, w.im, fma(b.im, w.re, a.im))};
+}
+__device__ __forceinline__ cd twice_minus(cd a, cd s) { return {fma(2.0, a.re, -s.re), fma(2.0, a.im, -s.im)}; }
+
+// Pre-twist by (1, w1, ..., w7), then dft8<S>: a forward level.  The products of the upper four points go straight into the first
+// butterfly stage (b = lo + hi*w: four FMAs) and the differences are recovered as 2 lo - b (two FMAs): 20 + 60 instructions
+// instead of the 28 + 60 of seven cmul and a dft8.  A recovered difference carries half an ulp of the larger of its two terms, so
+// the transform's error stays of the same order: exact at N = 1024, L = 3, outputs are bit-identical.
+template <int S>
+__device__ __forceinline__ void dft8_pretwist(cd (&x)[8], const cd w1, const cd w2, const cd w3, const cd w4, const cd w5, const cd w6,
+                                              const cd w7)
+{
+    const cd b0 = cfma_to(x[0], x[4], w4), d0 = twice_minus(x[0], b0);
+    const cd y1 = cmul(x[1], w1), b1 = cfma_to(y1, x[5], w5), t1 = twice_minus(y1, b1);
+    const cd y2 = cmul(x[2], w2), b2 = cfma_to(y2, x[6], w6), t2 = twice_minus(y2, b2);
+    const cd y3 = cmul(x[3], w3), b3 = cfma_to(y3, x[7], w7), t3 = twice_minus(y3, b3);
+    dft8_finish<S>(x, b0, b1, b2, b3, d0, t1, t2, t3);
 }
 
 // A wave's DS operations are executed in issue order, so a wave-private LDS exchange only
@@ -135,6 +161,14 @@ __device__ __forceinline__ void load_lane_twiddles(LaneTwiddles &tw, const cd *_
 // x[c] *= w^c (CONJ: conj(w)^c), c = 1..7, from w, w^2, w^4.  The empty asm makes w1 opaque so
 // the four derived powers are recomputed here instead of being hoisted out of the CMUX loop
 // (which would pin 16 more VGPRs per level and spills; an LDS table of them measured +3 %).
+// twist_pow<false> followed by dft8<1>, folded (dft8_pretwist); the same opaque-w1 rebuild of the derived powers
+__device__ __forceinline__ void twist_pow_dft8(cd (&x)[8], const TwPow &t)
+{
+    cd w1 = t.w1;
+    asm volatile("" : "+v"(w1.re), "+v"(w1.im));
+    const cd w3 = cmul(w1, t.w2), w5 = cmul(w1, t.w4), w6 = cmul(t.w2, t.w4), w7 = cmul(w3, t.w4);
+    dft8_pretwist<1>(x, w1, t.w2, w3, t.w4, w5, w6, w7);
+}
 template <bool CONJ> __device__ __forceinline__ void twist_pow(cd (&x)[8], const TwPow &t)
 {
     cd w1 = t.w1;
@@ -190,6 +224,11 @@ __device__ __forceinline__ void twist_all(cd (&x)[8], const TwPow &t, const TwAl
     x[1] = cmul(x[1], t.w1); x[2] = cmul(x[2], t.w2); x[3] = cmul(x[3], a.w3); x[4] = cmul(x[4], t.w4);
     x[5] = cmul(x[5], a.w5); x[6] = cmul(x[6], a.w6); x[7] = cmul(x[7], a.w7);
 }
+// twist_all followed by dft8<1>, folded (dft8_pretwist)
+__device__ __forceinline__ void twist_all_dft8(cd (&x)[8], const TwPow &t, const TwAll &a)
+{
+    dft8_pretwist<1>(x, t.w1, t.w2, a.w3, t.w4, a.w5, a.w6, a.w7);
+}
 __device__ __forceinline__ void twist_all_conj(cd (&x)[8], const TwPow &t, const TwAll &a)
 {
     x[1] = cmulc(x[1], t.w1); x[2] = cmulc(x[2], t.w2); x[3] = cmulc(x[3], a.w3); x[4] = cmulc(x[4], t.w4);
@@ -220,9 +259,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
                                                const LaneTwiddles &tw, int lane)
 {
     const int hi = lane >> 3, lo = lane & 7;
-#pragma unroll
-    for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
-    dft8<1>(x);
+    dft8_pretwist<1>(x, table[1], table[2], table[3], table[4], table[5], table[6], table[7]);
     // exchange 1: (reg m, lane 8b+c) -> (reg b, lane 8m+c)
 #pragma unroll
     for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[m];
@@ -230,8 +267,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int b = 0; b < 8; b++) x[b] = sc[SL1R(b)];
     wave_lds_order();
-    twist_pow<false>(x, tw.l2);
-    dft8<1>(x);
+    twist_pow_dft8(x, tw.l2);
     // exchange 2: (reg m', lane 8m+c) -> (reg c, lane 8m+m')
 #pragma unroll
     for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[mp];
@@ -239,8 +275,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
 #pragma unroll
     for (int c = 0; c < 8; c++) x[c] = sc[SL2R(c)];
     wave_lds_order();
-    twist_pow<false>(x, tw.l3);
-    dft8<1>(x);
+    twist_pow_dft8(x, tw.l3);
 }
 
 // The same transforms with the derived powers supplied by the caller (TwStep), no rebuild inside.
@@ -267,9 +302,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     const int hi = lane >> 3, lo = lane & 7;
     FFT_MIX1_BEGIN();
     if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_IN);
-#pragma unroll
-    for (int a = 1; a < 8; a++) x[a] = cmul(x[a], table[a]);
-    dft8<1>(x);
+    dft8_pretwist<1>(x, table[1], table[2], table[3], table[4], table[5], table[6], table[7]);
 #pragma unroll
     for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[m];
     wave_lds_order();
@@ -277,8 +310,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     for (int b = 0; b < 8; b++) x[b] = sc[SL1R(b)];
     wave_lds_order();
     FFT_MIX1(64);
-    twist_all(x, tw.l2, ts.l2);
-    dft8<1>(x);
+    twist_all_dft8(x, tw.l2, ts.l2);
 #pragma unroll
     for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[mp];
     wave_lds_order();
@@ -287,8 +319,7 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     wave_lds_order();
     FFT_MIX1(64);
     if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_OUT);
-    twist_all(x, tw.l3, ts.l3);
-    dft8<1>(x);
+    twist_all_dft8(x, tw.l3, ts.l3);
 }
 template <int PRIO_IN = -1, int PRIO_OUT = 0>
 __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__restrict__ table,
@@ -333,9 +364,7 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
     const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-#pragma unroll
-        for (int a = 1; a < 8; a++) x[t][a] = cmul(x[t][a], table[a]);
-        dft8<1>(x[t]);
+        dft8_pretwist<1>(x[t], table[1], table[2], table[3], table[4], table[5], table[6], table[7]);
         TFHE_PRIO(3);
 #pragma unroll
         for (int m = 0; m < 8; m++) sc[SL1W(m)] = x[t][m];
@@ -348,8 +377,7 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
     const TwAll a2 = expand_pow(tw.l2);        // once per batch, not per transform: -56 VALU per CMUX step at L = 3
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-        twist_all(x[t], tw.l2, a2);
-        dft8<1>(x[t]);
+        twist_all_dft8(x[t], tw.l2, a2);
         TFHE_PRIO(3);
 #pragma unroll
         for (int mp = 0; mp < 8; mp++) sc[SL2W(mp)] = x[t][mp];
@@ -362,8 +390,7 @@ __device__ __forceinline__ void fft512_forward_batch(cd (&x)[NB][8], cd *sc, con
     const TwAll a3 = expand_pow(tw.l3);
 #pragma unroll
     for (int t = 0; t < NB; t++) {
-        twist_all(x[t], tw.l3, a3);
-        dft8<1>(x[t]);
+        twist_all_dft8(x[t], tw.l3, a3);
     }
 }
 
@@ -407,9 +434,7 @@ __device__ __forceinline__ void fft512_forward_batch_pipe(cd (&x)[NB][8], cd *sc
         __builtin_amdgcn_sched_barrier(0);
     };
     auto level1 = [&](int t) {
-#pragma unroll
-        for (int a = 1; a < 8; a++) x[t][a] = cmul(x[t][a], table[a]);
-        dft8<1>(x[t]);
+        dft8_pretwist<1>(x[t], table[1], table[2], table[3], table[4], table[5], table[6], table[7]);
     };
     __builtin_amdgcn_sched_barrier(0);
     level1(0);
@@ -421,8 +446,7 @@ __device__ __forceinline__ void fft512_forward_batch_pipe(cd (&x)[NB][8], cd *sc
 #pragma unroll
     for (int t = 0; t < NB; t++) {
         if (t == 0) xchg1(NB - 1); else xchg2(t - 1);
-        twist_all(x[t], tw.l2, a2);
-        dft8<1>(x[t]);
+        twist_all_dft8(x[t], tw.l2, a2);
         mix();
     }
     before_last_level();
@@ -430,8 +454,7 @@ __device__ __forceinline__ void fft512_forward_batch_pipe(cd (&x)[NB][8], cd *sc
 #pragma unroll
     for (int t = 0; t < NB; t++) {
         if (t == 0) { xchg2(NB - 1); }
-        twist_all(x[t], tw.l3, a3);
-        dft8<1>(x[t]);
+        twist_all_dft8(x[t], tw.l3, a3);
         if (t == 0) mix();
     }
 }

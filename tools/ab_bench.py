@@ -24,10 +24,13 @@ step = (lambda: ck.ctx.gate_batch_dev("NAND", a, b, None, out)) if pname in ("80
 for _ in range(3): step()
 torch.cuda.synchronize()
 br, ks = [], []
-for _ in range(L):
-    step(); torch.cuda.synchronize()
-    br.append(ck.ctx.last_kernel_ms(0)); ks.append(ck.ctx.last_kernel_ms(1))
-print(json.dumps({"br": br, "ks": ks}))
+from go_tfhe_amd import telemetry
+smp = telemetry.Sampler(0, period_s=0.005)
+with smp:
+    for _ in range(L):
+        step(); torch.cuda.synchronize()
+        br.append(ck.ctx.last_kernel_ms(0)); ks.append(ck.ctx.last_kernel_ms(1))
+print(json.dumps({"br": br, "ks": ks, "tel": smp.summary()}))
 ''' % ROOT
 
 ap = argparse.ArgumentParser()
@@ -37,7 +40,7 @@ ap.add_argument("--launches", type=int, default=12)
 ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--params", default="128", help="parameter set name (go-tfhe_amd/params.py BY_NAME)")
 args = ap.parse_args()
-res = {l: {"br": [], "ks": []} for l in args.libs}
+res = {l: {"br": [], "ks": [], "clk": [], "pw": []} for l in args.libs}
 for r in range(args.rounds):
     for l in args.libs:
         env = dict(os.environ)
@@ -50,7 +53,12 @@ for r in range(args.rounds):
         except Exception:
             print("FAILED", l, out.stderr[-400:]); continue
         res[l]["br"] += d["br"]; res[l]["ks"] += d["ks"]
+        if d.get("tel", {}).get("available"):
+            res[l]["clk"].append(d["tel"].get("sclk_mhz_mean", 0)); res[l]["pw"].append(d["tel"].get("power_w_max", 0))
 for l in args.libs:
     br, ks = res[l]["br"], res[l]["ks"]
     if br:
-        print(f"{os.path.basename(l):28s} BR mean {sum(br)/len(br):.3f} min {min(br):.3f} max {max(br):.3f} | KS mean {sum(ks)/len(ks):.3f} min {min(ks):.3f}  (n={len(br)})")
+        tel = ""
+        if res[l]["clk"]:
+            tel = f" | sclk {sum(res[l]['clk'])/len(res[l]['clk']):.0f} MHz, power max {max(res[l]['pw']):.0f} W"
+        print(f"{os.path.basename(l):28s} BR mean {sum(br)/len(br):.3f} min {min(br):.3f} max {max(br):.3f} | KS mean {sum(ks)/len(ks):.3f} min {min(ks):.3f}  (n={len(br)}){tel}")

@@ -1,0 +1,15 @@
+#!/bin/bash
+# tools/r04_collect.sh <tag>: GPU tests, bench line, the same command under rocprofv3 --kernel-trace --stats, PMC passes (128-bit x 1,024 and Uint5 x 512)
+TAG=${1:-r04c}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R
+python -m pytest tests -m gpu -x -q > $OUT/pytest.txt 2>&1; tail -2 $OUT/pytest.txt
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err )
+find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_u5 -- python $R/tools/pmc_workload.py uint5 512 12 > $OUT/u5_under_rocprof.log 2>&1 )
+find $OUT/stats_u5 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_uint5.csv \;
+tools/prof_pmc.sh $TAG/pmc128 1024 > $OUT/pmc128.log 2>&1
+tools/prof_pmc.sh $TAG/pmcu5 512 uint5 > $OUT/pmcu5.log 2>&1
+rm -rf $OUT/stats $OUT/stats_u5 $OUT/pmc128/*/ $OUT/pmcu5/*/
+ls $OUT
