@@ -414,11 +414,14 @@ class Context:
         self._check(self._lib.tfhe_key_import_dev(self._h, int(which), C.c_void_p(blob.data_ptr()),
                                                   blob.numel() * blob.element_size(), self._stream(stream)))
 
-    OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4}
+    OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4, "combine_max": 5, "combine_launches": 6,
+               "combine_requests": 7}
 
     def set_option(self, name, value):
         """tfhe_ctx_set_option: kernel-dispatch limits for measurements and tests ("quad_max", "oct_max", "ks_mfma_min";
-        a negative value restores the default) and the "frozen" flag (include/tfhe_hip.h)."""
+        a negative value restores the default), the "frozen" flag, and "combine_max" -- the largest gate_batch call that is
+        combined with concurrent callers' (0 = never; "combine_launches" / "combine_requests" are read-only counters)
+        (include/tfhe_hip.h)."""
         self._check(self._lib.tfhe_ctx_set_option(self._h, self.OPTIONS[name], int(value)))
 
     def get_option(self, name):

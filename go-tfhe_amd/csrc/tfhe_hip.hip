@@ -15,7 +15,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <deque>
+#include <condition_variable>
 #include <string>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 #include "kernels.hpp"
@@ -117,6 +121,20 @@ struct tfhe_ctx {
     // staging (grow-only)
     DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_plan, s_t0, s_t1, s_t2, s_t3;
     std::recursive_mutex mu;    // host-pointer calls hold it for their whole duration, _dev calls while they reserve and enqueue
+    // Flat combining of concurrent tfhe_gate_batch callers (combine_gate_request below): requests that arrive while a
+    // launch is in flight queue here, and the next leader issues ALL of them as one gate batch.
+    struct GateReq {
+        const uint8_t *ops; int op_uniform; const uint32_t *a, *b, *cc; uint32_t *out; int B;
+        int rc = TFHE_OK; std::string err; bool done = false, lead = false;
+        std::condition_variable cv;     // one per waiting caller: a finished launch wakes the callers it carried and the next leader, nobody else
+    };
+    std::mutex comb_mu;
+    std::deque<GateReq *> comb_pending;
+    bool comb_leader = false;   // some thread is executing (or about to execute) combined launches
+    int combine_max = 0;        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
+    void *comb_host = nullptr;  // page-locked staging of one combined launch: [a | b | c | out][rows][n+1] + op codes
+    size_t comb_host_cap = 0;
+    long long comb_launches = 0, comb_requests = 0;     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
 };
 
 namespace {
@@ -715,6 +733,149 @@ int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const 
     return TFHE_OK;
 }
 
+// The host-pointer gate batch of ONE caller: stage, launch, read back, under the context mutex.
+int gate_batch_serial(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b, const uint32_t *cc,
+                      uint32_t *out, int B)
+{
+    int rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (B > pipe_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
+    const size_t rows = (size_t)B * (c->P.n + 1) * 4;
+    if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_in1.reserve(rows)) || (rc = c->s_out.reserve(rows))) return rc;
+    if (cc && (rc = c->s_in2.reserve(rows))) return rc;
+    if (ops && (rc = c->s_ops.reserve(B))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, a, rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_in1.p, b, rows, hipMemcpyHostToDevice, c->stream));
+    if (cc) HIP_TRY(hipMemcpyAsync(c->s_in2.p, cc, rows, hipMemcpyHostToDevice, c->stream));
+    if (ops) HIP_TRY(hipMemcpyAsync(c->s_ops.p, ops, B, hipMemcpyHostToDevice, c->stream));
+    if ((rc = gate_batch_device(c, ops ? c->s_ops.as<uint8_t>() : nullptr, op_uniform, c->s_in0.as<uint32_t>(),
+                                c->s_in1.as<uint32_t>(), cc ? c->s_in2.as<uint32_t>() : nullptr,
+                                c->s_out.as<uint32_t>(), B, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+// One launch for the requests of several callers: their rows are packed behind one another in page-locked staging
+// (one host copy per operand and request, ONE transfer per operand plane), every item carries its own op code, and
+// each caller gets its rows back.  A gate's result depends on its own operands only -- not on its position in a batch,
+// not on the batch's size or kernel shape (tests: batch-position invariance) -- so every caller receives exactly the
+// words the serial path would have given it.
+int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
+{
+    int rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t n1 = (size_t)c->P.n + 1;
+    size_t total = 0;
+    bool any_c = false;
+    for (auto *r : batch) { total += (size_t)r->B; any_c = any_c || r->cc; }
+    const size_t plane = total * n1 * 4, planes = any_c ? 4 : 3;          // a, b, [c], out
+    const size_t need = planes * plane + total;
+    if (need > c->comb_host_cap) {
+        if (c->comb_host) (void)hipHostFree(c->comb_host);
+        c->comb_host = nullptr; c->comb_host_cap = 0;
+        const size_t cap = need < ((size_t)1 << 22) ? ((size_t)1 << 22) : need + need / 2;
+        hipError_t e = hipHostMalloc(&c->comb_host, cap, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        c->comb_host_cap = cap;
+    }
+    char *ha = static_cast<char *>(c->comb_host), *hb = ha + plane, *hc = any_c ? hb + plane : nullptr;
+    char *ho = ha + (planes - 1) * plane;
+    uint8_t *hops = reinterpret_cast<uint8_t *>(ha + planes * plane);
+    size_t at = 0;
+    for (auto *r : batch) {
+        const size_t bytes = (size_t)r->B * n1 * 4;
+        memcpy(ha + at * n1 * 4, r->a, bytes);
+        memcpy(hb + at * n1 * 4, r->b, bytes);
+        if (hc) {
+            if (r->cc) memcpy(hc + at * n1 * 4, r->cc, bytes);
+            else memset(hc + at * n1 * 4, 0, bytes);                      // never read: none of this request's ops is MUX
+        }
+        if (r->ops) memcpy(hops + at, r->ops, (size_t)r->B);
+        else memset(hops + at, r->op_uniform, (size_t)r->B);
+        at += (size_t)r->B;
+    }
+    if ((rc = c->s_in0.reserve(plane)) || (rc = c->s_in1.reserve(plane)) || (rc = c->s_out.reserve(plane))) return rc;
+    if (any_c && (rc = c->s_in2.reserve(plane))) return rc;
+    if ((rc = c->s_ops.reserve(total))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, ha, plane, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_in1.p, hb, plane, hipMemcpyHostToDevice, c->stream));
+    if (any_c) HIP_TRY(hipMemcpyAsync(c->s_in2.p, hc, plane, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_ops.p, hops, total, hipMemcpyHostToDevice, c->stream));
+    if ((rc = gate_batch_device(c, c->s_ops.as<uint8_t>(), 0, c->s_in0.as<uint32_t>(), c->s_in1.as<uint32_t>(),
+                                any_c ? c->s_in2.as<uint32_t>() : nullptr, c->s_out.as<uint32_t>(), (int)total, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(ho, c->s_out.p, plane, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    at = 0;
+    for (auto *r : batch) {
+        memcpy(r->out, ho + at * n1 * 4, (size_t)r->B * n1 * 4);
+        at += (size_t)r->B;
+    }
+    c->comb_launches++;
+    c->comb_requests += (long long)batch.size();
+    return TFHE_OK;
+}
+
+// Flat combining (the reference's concurrency is goroutine fan-out over pooled evaluators, trgsw.go:227-252; its scalar
+// gates.* serialise on one evaluator, gates.go:19-23,136-142).  A launch of 1 ... 256 bootstraps costs the same 2.4 ms, so N
+// threads issuing scalar gates one launch each would get N x 2.4 ms.  Instead: a caller that finds no launch in flight
+// becomes the LEADER and issues its request at once (a lone caller's latency is unchanged: its request is launched as it
+// always was); callers that arrive meanwhile queue; when the leader's launch is done it hands leadership to the oldest
+// waiter, which issues EVERYTHING queued as one gate batch and distributes the rows.  No timer, no extra thread.
+int combine_gate_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
+{
+    std::unique_lock<std::mutex> lk(c->comb_mu);
+    c->comb_pending.push_back(&me);
+    if (c->comb_leader) {
+        me.cv.wait(lk, [&] { return me.done || me.lead; });
+        if (me.done) {
+            if (me.rc) g_err = me.err;
+            return me.rc;
+        }
+        // Promoted under contention.  The callers the previous launch carried are waking up this very moment and will be back
+        // with their next request within microseconds; launching without them makes two cohorts that take turns (each launch
+        // half as full as it could be at the same cost).  Let them queue: re-check the queue a few times, at most ~200 us --
+        // 8 % of the launch this wait precedes -- and stop as soon as it no longer grows.  A lone caller never gets here.
+        size_t seen = c->comb_pending.size();
+        for (int round = 0, still = 0; round < 10 && still < 2; round++) {
+            lk.unlock();
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+            lk.lock();
+            still = c->comb_pending.size() == seen ? still + 1 : 0;
+            seen = c->comb_pending.size();
+        }
+    } else {
+        c->comb_leader = true;
+    }
+    // leader: `me` is the oldest pending request; take it and as many of the following as one launch may carry
+    std::vector<tfhe_ctx::GateReq *> batch;
+    const int cap = pipe_items(c);
+    int total = 0;
+    while (!c->comb_pending.empty() && (batch.empty() || total + c->comb_pending.front()->B <= cap)) {
+        batch.push_back(c->comb_pending.front());
+        total += c->comb_pending.front()->B;
+        c->comb_pending.pop_front();
+    }
+    lk.unlock();
+    int rc;
+    if (batch.size() == 1) rc = gate_batch_serial(c, me.ops, me.op_uniform, me.a, me.b, me.cc, me.out, me.B);
+    else rc = run_combined(c, batch);
+    const std::string err = rc ? g_err : std::string();
+    lk.lock();
+    for (auto *r : batch) {
+        r->rc = rc;
+        if (rc) r->err = err;
+        r->done = true;
+        if (r != &me) r->cv.notify_one();               // under the lock: a woken caller's request object dies when it returns
+    }
+    if (c->comb_pending.empty()) c->comb_leader = false;
+    else {                                              // leadership passes to the oldest waiter
+        c->comb_pending.front()->lead = true;
+        c->comb_pending.front()->cv.notify_one();
+    }
+    return rc;
+}
+
 // Reads and clears the device status word (after the caller has synchronised the stream the work ran on).
 int check_status(tfhe_ctx *c)
 {
@@ -777,6 +938,7 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     c->quad_limit = c->num_cus;
     c->oct_limit = c->num_cus;
     c->ks_mfma_min = kKsMfmaMinDefault;
+    c->combine_max = launch_items(c);      // requests of up to one launch's worth of gates are combined (tfhe_gate_batch)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
@@ -815,6 +977,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     for (auto &v : c->tev)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->comb_host) (void)hipHostFree(c->comb_host);
     for (auto &pr : c->pipe_ev)
         for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {c->h2d_stream, c->d2h_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -856,6 +1019,7 @@ int tfhe_ctx_set_option(tfhe_ctx *c, int option, int value)
         }
         return TFHE_OK;
     case TFHE_OPT_FROZEN: c->frozen = value != 0; return TFHE_OK;
+    case TFHE_OPT_COMBINE_MAX: c->combine_max = value < 0 ? launch_items(c) : value; return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);
     }
 }
@@ -869,6 +1033,9 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_OCT_MAX: *value = c->oct_limit; return TFHE_OK;
     case TFHE_OPT_KS_MFMA_MIN: *value = c->ks_mfma_min; return TFHE_OK;
     case TFHE_OPT_FROZEN: *value = c->frozen ? 1 : 0; return TFHE_OK;
+    case TFHE_OPT_COMBINE_MAX: *value = c->combine_max; return TFHE_OK;
+    case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)c->comb_launches; return TFHE_OK;
+    case TFHE_OPT_COMBINE_REQUESTS: *value = (int)c->comb_requests; return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);
     }
 }
@@ -1326,23 +1493,13 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
             if (ops[i] > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d at item %d", ops[i], i);
             if (ops[i] == TFHE_OP_MUX && !cc) return fail(TFHE_E_INVALID, "MUX needs the third operand");
         }
+    } else {
+        if (op_uniform < 0 || op_uniform > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d", op_uniform);
+        if (op_uniform == TFHE_OP_MUX && !cc) return fail(TFHE_E_INVALID, "MUX needs the third operand");
     }
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    if (B > pipe_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
-    const size_t rows = (size_t)B * (c->P.n + 1) * 4;
-    if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_in1.reserve(rows)) || (rc = c->s_out.reserve(rows))) return rc;
-    if (cc && (rc = c->s_in2.reserve(rows))) return rc;
-    if (ops && (rc = c->s_ops.reserve(B))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->s_in0.p, a, rows, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->s_in1.p, b, rows, hipMemcpyHostToDevice, c->stream));
-    if (cc) HIP_TRY(hipMemcpyAsync(c->s_in2.p, cc, rows, hipMemcpyHostToDevice, c->stream));
-    if (ops) HIP_TRY(hipMemcpyAsync(c->s_ops.p, ops, B, hipMemcpyHostToDevice, c->stream));
-    if ((rc = gate_batch_device(c, ops ? c->s_ops.as<uint8_t>() : nullptr, op_uniform, c->s_in0.as<uint32_t>(),
-                                c->s_in1.as<uint32_t>(), cc ? c->s_in2.as<uint32_t>() : nullptr,
-                                c->s_out.as<uint32_t>(), B, c->stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, rows, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return TFHE_OK;
+    if (B > c->combine_max) return gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
+    tfhe_ctx::GateReq me{ops, op_uniform, a, b, cc, out, B};
+    return combine_gate_request(c, me);
 }
 
 int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, uint32_t *out, int B)

@@ -109,8 +109,12 @@ enum {
     TFHE_OPT_OCT_MAX = 2,      /* ... and of those, up to this many the eight-wave kernel; default = number of CUs       */
     TFHE_OPT_KS_MFMA_MIN = 3,  /* batches of at least this many ciphertexts use the matrix-core key switch where the key
                                   shape has one (default 1); 0 = never (the vector-ALU kernels)                          */
-    TFHE_OPT_FROZEN = 4        /* 1 while a captured hipGraph may hold the intermediate buffers' addresses (set by the
+    TFHE_OPT_FROZEN = 4,       /* 1 while a captured hipGraph may hold the intermediate buffers' addresses (set by the
                                   library, see tfhe_ctx_reserve); the caller clears it once those graphs are destroyed    */
+    TFHE_OPT_COMBINE_MAX = 5,  /* tfhe_gate_batch calls of at most this many gates are COMBINED with concurrent callers'
+                                  (see tfhe_gate_batch); default (and -1) = one launch's worth, 0 = never                  */
+    TFHE_OPT_COMBINE_LAUNCHES = 6,  /* read-only: combined launches issued so far ...                                       */
+    TFHE_OPT_COMBINE_REQUESTS = 7   /* ... and the tfhe_gate_batch calls they carried                                       */
 };
 int tfhe_ctx_set_option(tfhe_ctx *ctx, int option, int value);
 int tfhe_ctx_get_option(tfhe_ctx *ctx, int option, int *value);
@@ -219,7 +223,16 @@ int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, 
  * MUX items are found and compacted on the device (no op code is ever copied back): one blind-rotate request
  * covers every item's own gate (a MUX item's AND(a,b)) plus ANDNY(a,c) of the MUX items, a second one their OR.
  * The host-pointer variant validates the op codes before issuing anything; the _dev variant cannot (see
- * tfhe_ctx_sync). */
+ * tfhe_ctx_sync).
+ *
+ * Concurrent callers of the host-pointer variant (any number of threads on ONE context) are COMBINED, not serialised: a
+ * launch of 1 ... 256 bootstraps costs the same ~2.4 ms, so while one caller's launch is in flight the others queue, and the
+ * next launch carries ALL queued requests as one gate batch with per-item op codes; each caller gets exactly its rows back --
+ * bit-identical to what a call on its own returns (a gate's result depends on its own operands only).  There is no timer
+ * and no extra thread: a lone caller is launched at once, exactly as before.  Calls of more than TFHE_OPT_COMBINE_MAX gates
+ * take the context for themselves.  (The reference's scalar gates.* share one evaluator that is not goroutine-safe,
+ * gates.go:19-23; its concurrency is one pooled evaluator per goroutine, trgsw.go:227-252 -- this is what replaces it.)
+ * If a combined launch fails, every call it carried returns that error. */
 int tfhe_gate_batch(tfhe_ctx *ctx, const uint8_t *ops, int op_uniform, const uint32_t *a,
                     const uint32_t *b, const uint32_t *c, uint32_t *out, int B);
 int tfhe_gate_batch_dev(tfhe_ctx *ctx, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a,

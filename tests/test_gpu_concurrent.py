@@ -1,0 +1,148 @@
+"""GPU tier: concurrent submitters on ONE context are combined, not serialised (include/tfhe_hip.h, tfhe_gate_batch).
+
+The reference's scalar gates.* share one evaluator that is not goroutine-safe (gates.go:19-23,136-142); its concurrency is
+goroutine fan-out over pooled evaluators (trgsw.go:227-252).  Here any number of threads may call gates.* on one CloudKey:
+requests that arrive while a launch is in flight are issued together as ONE gate batch with per-item op codes (flat
+combining), and each caller gets exactly the rows a call on its own would have returned."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _adder_inputs(k, pkg, C, bits, seed):
+    rs = np.random.RandomState(seed)
+    av, bv = rs.randint(0, 256, C), rs.randint(0, 256, C)
+    n1 = k.p.n + 1
+    a_bits = np.stack([k.enc((av >> i) & 1) for i in range(bits)])        # [bits][C][n1]
+    b_bits = np.stack([k.enc((bv >> i) & 1) for i in range(bits)])
+    return av, bv, a_bits, b_bits, n1
+
+
+def test_256_threads_issuing_scalar_gates_are_combined_and_bit_identical(oracle, keys128, ck128, pkg):
+    # 256 threads, each adding two encrypted bytes with the reference's 40 scalar gate calls IN SEQUENCE (README.md:78-106),
+    # all on one context.  Serialised that is 256 x 40 launches of ~2.5 ms = 25 s; combined it is ~40 launches of <= 256 gates.
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor
+    g = pkg.gates
+    k, ctx = keys128, ck128.ctx
+    C, bits = 256, 8
+    av, bv, a_bits, b_bits, n1 = _adder_inputs(k, pkg, C, bits, 77)
+    const_false = g.Constant(False, k.p)
+    sums = np.zeros((C, bits + 1, n1), np.uint32)
+
+    def add_bytes(c):                                    # one caller: the README's FullAdder chain, gate by gate
+        carry = const_false
+        for i in range(bits):
+            x = g.XOR(a_bits[i, c], b_bits[i, c], ck128)
+            gen = g.AND(a_bits[i, c], b_bits[i, c], ck128)
+            sums[c, i] = g.XOR(x, carry, ck128)
+            t = g.AND(x, carry, ck128)
+            carry = g.OR(gen, t, ck128)
+        sums[c, bits] = carry
+
+    add_bytes(0)                                         # warm-up (and the lone-caller path: no combined launch)
+    assert ctx.get_option("combine_launches") == 0
+    threads = [threading.Thread(target=add_bytes, args=(c,)) for c in range(C)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt_threads = time.perf_counter() - t0
+    launches, carried = ctx.get_option("combine_launches"), ctx.get_option("combine_requests")
+
+    # the same 256 additions through the levelised batch executor: every output word must be identical
+    levels, n_wires, sum_w, cout = ripple_carry_adder(bits, fold_carry_in=False)
+    wires = np.zeros((n_wires, C, n1), np.uint32)
+    wires[:bits] = a_bits
+    wires[bits:2 * bits] = b_bits
+    wires[adder_constant_wire(bits)] = const_false
+    wt = torch.from_numpy(wires.view(np.int32)).cuda()
+    ex = CircuitExecutor(ctx, levels, n_wires)
+    ex.run(wt.clone()); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ex.run(wt); torch.cuda.synchronize()
+    dt_exec = time.perf_counter() - t0
+    res = wt.cpu().numpy().view(np.uint32)
+    for i, w in enumerate(sum_w):
+        assert np.array_equal(sums[:, i], res[w]), f"sum bit {i} differs from the batch path"
+    assert np.array_equal(sums[:, bits], res[cout])
+    got = sum(k.dec(np.ascontiguousarray(sums[:, i])).astype(np.int64) << i for i in range(bits + 1))
+    assert np.array_equal(got, av + bv)
+
+    # combined: far fewer launches than requests, and a wall time in the region of 40 sequential launches, not 10,240.
+    # (40 dependent rounds x ~2.6 ms is ~105 ms of kernels against the executor's 17 levels; the rest is 256 Python threads
+    # taking turns at the interpreter lock -- the C++ measurement is tools/combine_bench.cpp.)
+    assert carried >= 0.9 * 40 * C and launches <= carried / 8, (launches, carried)
+    print(f"\n256 threads x 40 scalar gates: {dt_threads * 1e3:.0f} ms in {launches} combined launches carrying {carried} calls "
+          f"(+ {40 * C - carried} lone); CircuitExecutor x256: {dt_exec * 1e3:.0f} ms")
+    assert dt_threads < 40 * C * 2.4e-3 / 10, "concurrent scalar gates are being serialised"
+
+
+def test_combined_mixed_requests_equal_serial_results(oracle, keys_small, ck_small, pkg):
+    # callers with different shapes at once: uniform ops, per-item ops with MUX (third operand), batches of several rows --
+    # each result equals the same call issued alone with combining switched off
+    k, ctx = keys_small, ck_small.ctx
+    rs = np.random.RandomState(5)
+    n1 = k.p.n + 1
+    rnd = lambda B: rs.randint(0, 2**32, size=(B, n1), dtype=np.uint64).astype(np.uint32)
+    reqs = []
+    for i in range(48):
+        B = [1, 1, 3, 17][i % 4]
+        a, b, c = rnd(B), rnd(B), rnd(B)
+        if i % 3 == 0:
+            reqs.append(("XOR", a, b, None))
+        elif i % 3 == 1:
+            reqs.append((np.array([10, 1, 2, 0, 4, 9, 10] * 3, np.uint8)[:B], a, b, c))
+        else:
+            reqs.append(("MUX", a, b, c))
+    ctx.set_option("combine_max", 0)
+    want = [ctx.gate_batch(op, a, b, c) for op, a, b, c in reqs]
+    ctx.set_option("combine_max", -1)
+    before = ctx.get_option("combine_requests")
+    got = [None] * len(reqs)
+    gate = threading.Barrier(len(reqs))
+
+    def run(i):
+        op, a, b, c = reqs[i]
+        gate.wait()
+        got[i] = ctx.gate_batch(op, a, b, c)
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(len(reqs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(len(reqs)):
+        assert np.array_equal(got[i], want[i]), f"request {i} differs from the serial path"
+    assert ctx.get_option("combine_requests") > before          # at least some of them travelled together
+
+
+def test_combined_launch_error_reaches_every_caller_and_the_context_survives(keys_small, ck_small, pkg):
+    # a bad op code is refused per call, before queueing: the other callers are not affected
+    k, ctx = keys_small, ck_small.ctx
+    rs = np.random.RandomState(6)
+    n1 = k.p.n + 1
+    a = rs.randint(0, 2**32, size=(1, n1), dtype=np.uint64).astype(np.uint32)
+    errs, oks = [], []
+
+    def bad():
+        try:
+            ctx.gate_batch(np.array([77], np.uint8), a, a)
+        except pkg.TfheError as e:
+            errs.append(str(e))
+
+    def good():
+        oks.append(ctx.gate_batch("AND", a, a))
+
+    ts = [threading.Thread(target=bad if i % 2 else good) for i in range(16)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(errs) == 8 and all("bad op code" in e for e in errs)
+    assert len(oks) == 8 and all(np.array_equal(o, oks[0]) for o in oks)

@@ -1,0 +1,69 @@
+// tools/combine_bench.cpp -- concurrent submitters on ONE context through the C ABI, without an interpreter lock:
+//   T threads each issue the reference adder's 40 scalar gate calls in sequence (README.md:78-106: XOR, AND, XOR, AND, OR per
+//   bit; every call waits for its result) on one tfhe_ctx; prints the wall time, the combined launches and the calls they carried,
+//   and the same with combining switched off (TFHE_OPT_COMBINE_MAX = 0) for a few threads.
+// Random key and random operands: timing does not depend on the values.
+//   g++ -O2 -std=c++17 tools/combine_bench.cpp -o tools/combine_bench.bin -Lgo-tfhe_amd/lib -ltfhe_hip -Wl,-rpath,'$ORIGIN/../go-tfhe_amd/lib' -Wl,-rpath,/opt/rocm/lib -lpthread
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../include/tfhe_hip.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_) { std::printf("FAILED %s: %s\n", #x, tfhe_last_error()); std::exit(1); } } while (0)
+
+int main(int argc, char **argv)
+{
+    const int T = argc > 1 ? std::atoi(argv[1]) : 256;
+    tfhe_params P{700, 1024, 10, 3, 6, 2, 9};                 // 128-bit set (params.go:151-180)
+    tfhe_ctx *ctx = nullptr;
+    CK(tfhe_ctx_create(&P, 0, &ctx));
+    std::mt19937_64 gen(7);
+    std::vector<uint32_t> s0(P.n), s1(P.N);
+    for (auto &v : s0) v = gen() & 1;
+    for (auto &v : s1) v = gen() & 1;
+    CK(tfhe_keygen_cloud(ctx, s0.data(), s1.data(), 2.0e-5, 2.0e-8, 11));
+    const int n1 = P.n + 1;
+    std::vector<std::vector<uint32_t>> in(T, std::vector<uint32_t>((size_t)16 * n1));
+    for (auto &v : in) for (auto &w : v) w = (uint32_t)gen();
+
+    auto adder = [&](int t) {
+        std::vector<uint32_t> x(n1), g(n1), s(n1), u(n1), carry(n1, 0u), nc(n1);
+        carry[P.n] = 0xE0000001u;                              // gates.Constant(false), gates.go:61-69
+        for (int i = 0; i < 8; i++) {
+            const uint32_t *a = in[t].data() + (size_t)i * n1, *b = in[t].data() + (size_t)(8 + i) * n1;
+            CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_XOR, a, b, nullptr, x.data(), 1));
+            CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_AND, a, b, nullptr, g.data(), 1));
+            CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_XOR, x.data(), carry.data(), nullptr, s.data(), 1));
+            CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_AND, x.data(), carry.data(), nullptr, u.data(), 1));
+            CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_OR, g.data(), u.data(), nullptr, nc.data(), 1));
+            carry.swap(nc);
+        }
+    };
+    auto run = [&](int threads) {
+        std::vector<std::thread> th;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < threads; t++) th.emplace_back(adder, t);
+        for (auto &x : th) x.join();
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    adder(0);                                                  // warm-up
+    int l0, r0, l1, r1;
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_LAUNCHES, &l0));
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_REQUESTS, &r0));
+    const double one = run(1);
+    const double ms = run(T);
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_LAUNCHES, &l1));
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_REQUESTS, &r1));
+    CK(tfhe_ctx_set_option(ctx, TFHE_OPT_COMBINE_MAX, 0));
+    const int Ts = T < 8 ? T : 8;
+    const double serial = run(Ts);
+    std::printf("{\"threads\": %d, \"gate_calls\": %d, \"ms\": %.1f, \"combined_launches\": %d, \"calls_carried\": %d, "
+                "\"one_thread_40_gates_ms\": %.1f, \"serialised_%d_threads_ms\": %.1f, \"serialised_all_threads_projected_ms\": %.0f}\n",
+                T, 40 * T, ms, l1 - l0, r1 - r0, one, Ts, serial, serial / Ts * T);
+    CK(tfhe_ctx_destroy(ctx));
+    return 0;
+}
