@@ -147,6 +147,13 @@ orc_fft *orc_fft_new(int N)
     return f;
 }
 
+void orc_fft_twiddles(const orc_fft *f, double *tw_re, double *tw_im, double *twinv_re, double *twinv_im)
+{
+    size_t bytes = sizeof(double) * (size_t)(f->M - 1);
+    memcpy(tw_re, f->tw_re, bytes); memcpy(tw_im, f->tw_im, bytes);
+    memcpy(twinv_re, f->twi_re, bytes); memcpy(twinv_im, f->twi_im, bytes);
+}
+
 void orc_fft_free(orc_fft *f)
 {
     if (!f) return;

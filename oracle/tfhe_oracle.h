@@ -56,6 +56,9 @@ uint32_t orc_decomposition_offset(const orc_params *p);   /* cloudkey/cloudkey.g
 typedef struct orc_fft orc_fft;
 orc_fft *orc_fft_new(int N);
 void     orc_fft_free(orc_fft *f);
+/* The evaluator's tw / twInv tables (poly_evaluator.go:114-143), N/2 - 1 complex entries each, for tests that run another
+ * statement of fftInPlace / ifftInPlace on the very same twiddles (tests/go_fft_shapes.py). */
+void     orc_fft_twiddles(const orc_fft *f, double *tw_re, double *tw_im, double *twinv_re, double *twinv_im);
 
 /* ToFourierPolyAssign: fold + forward FFT (fourier_transform.go:18-21,64-85,178-247).
  * fp has N doubles in the reference FourierPoly layout ([4 re | 4 im] blocks). */

@@ -88,6 +88,13 @@ class Oracle:
             self._fft[N] = C.c_void_p(self.lib.orc_fft_new(N))
         return self._fft[N]
 
+    def fft_twiddles(self, N):
+        """(tw, twInv) of the evaluator for ring degree N as complex128 arrays of N/2 - 1 entries (poly_evaluator.go:114-143)."""
+        M = N // 2
+        arrs = [np.empty(M - 1, np.float64) for _ in range(4)]
+        self.lib.orc_fft_twiddles(self.fft(N), *[_f64p(a) for a in arrs])
+        return arrs[0] + 1j * arrs[1], arrs[2] + 1j * arrs[3]
+
     def rng(self, seed):
         r = Rng()
         self.lib.orc_rng_seed(C.byref(r), C.c_uint64(seed))

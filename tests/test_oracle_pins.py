@@ -230,3 +230,43 @@ def test_golden_bootstrap_chain(oracle):
         acc = oracle.blind_rotate(ks.p, ks.bsk, ct, ks.tv)
         assert np.array_equal(acc, g["trlwe_acc"][i])
         assert np.array_equal(oracle.key_switch(ks.p, ks.ksk, oracle.sample_extract(acc)), g["lwe_out"][i])
+
+
+# ---- the oracle's one restructuring, held to the reference's own loop structure --------------------
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_generic_fft_loop_equals_the_four_stage_shapes_bitwise(oracle, N):
+    """oracle/tfhe_oracle.c runs fftInPlace / ifftInPlace as one generic loop over complex slots; the reference writes four
+    (three) stage shapes over [4 re | 4 im] blocks (fourier_transform.go:178-347).  tests/go_fft_shapes.py keeps the
+    reference's structure; on the SAME twiddle table both must produce the same doubles bit for bit -- the spectra a Go shim
+    would upload through tfhe_load_bsk_fourier are in exactly this slot order.  (Pins the oracle's restructuring; says nothing
+    about the Go binary's own bits -- parity stays 'unpinned')"""
+    import go_fft_shapes as g
+    tw, tw_inv = oracle.fft_twiddles(N)
+    tw, tw_inv = [complex(x) for x in tw], [complex(x) for x in tw_inv]
+    rs = np.random.RandomState(N)
+    p = rs.randint(0, 2**32, size=N, dtype=np.uint64).astype(np.uint32)
+    want = oracle.to_fourier(p)
+    c = g.fold(p)
+    g.fft_in_place(c, tw)
+    got = np.array(c)
+    assert got.tobytes() == want.tobytes(), f"forward: {np.count_nonzero(got != want)} of {N} doubles differ"
+    # inverse on a spectrum of realistic magnitude (a product of two transforms' size), pre-rounding doubles compared
+    spec = want * 1024.0 + rs.standard_normal(N) * 2.0**40
+    _, pre = oracle.to_poly(spec, want_pre=True)
+    c = [float(x) for x in spec]
+    g.ifft_in_place(c, tw_inv)
+    got = np.array(c)
+    assert got.tobytes() == pre.tobytes(), f"inverse: {np.count_nonzero(got != pre)} of {N} doubles differ"
+
+
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_twiddle_table_construction_follows_the_reference(oracle, N):
+    """genTwiddleFactors (poly_evaluator.go:114-143) restated with the reference's in-place bit reversal and fold factors:
+    same entries in the same order as the oracle's table.  cos / sin come from different libraries (Go's math.Sincos is a pure-Go
+    Cephes port, the oracle uses glibc, this test Python's cmath), so entries may differ in the last bit: <= 2 ulp, not bitwise."""
+    import go_fft_shapes as g
+    tw, tw_inv = oracle.fft_twiddles(N)
+    gtw, gtw_inv = g.gen_twiddle_factors(N // 2)
+    assert len(gtw) == len(tw) == N // 2 - 1 and len(gtw_inv) == len(tw_inv)
+    assert np.max(np.abs(np.array(gtw) - tw)) <= 4 * np.finfo(np.float64).eps
+    assert np.max(np.abs(np.array(gtw_inv) - tw_inv)) <= 4 * np.finfo(np.float64).eps
