@@ -66,6 +66,7 @@ def load_library():
         "tfhe_load_ksk": [vp, u32p],
         "tfhe_keygen_cloud": [vp, u32p, u32p, C.c_double, C.c_double, C.c_uint64],
         "tfhe_ctx_reserve": [vp, C.c_int, C.c_int],
+        "tfhe_ctx_reserve_extended": [vp, C.c_int, C.c_int],
         "tfhe_key_size": [vp, C.c_int, C.POINTER(C.c_size_t)],
         "tfhe_key_export_dev": [vp, C.c_int, vp, vp],
         "tfhe_key_import_dev": [vp, C.c_int, vp, C.c_size_t, vp],
@@ -432,6 +433,10 @@ class Context:
     def reserve(self, max_batch, with_mux=False):
         """Pre-size the intermediate buffers (needed before capturing _dev calls into a graph)."""
         self._check(self._lib.tfhe_ctx_reserve(self._h, int(max_batch), int(bool(with_mux))))
+
+    def reserve_extended(self, max_batch, ext):
+        """The same for bootstrap_extended_batch_dev with polyExtendFactor `ext` (its accumulators are not sized by reserve)."""
+        self._check(self._lib.tfhe_ctx_reserve_extended(self._h, int(max_batch), int(ext)))
 
     def timing_enable(self, on=True):
         self._check(self._lib.tfhe_timing_enable(self._h, int(bool(on))))

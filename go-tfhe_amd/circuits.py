@@ -193,23 +193,35 @@ class CircuitExecutor:
             uniform = lvl[0][0] if len(set(g[0] for g in lvl)) == 1 else None
             self._plan.append((ops, uniform, i0, i1, i2, out))
         self._op_cache = {}                      # (level, C) -> per-item op codes on the device
+        self._captured = False
 
-    def capture(self, wires):
+    def capture(self, wires, max_instances=None):
         """Record run(wires) into a HIP graph (torch.cuda.CUDAGraph) and return it; replay() re-runs the whole
         circuit on whatever the wire tensor holds at that time.  tfhe_gate_batch_dev only enqueues (no read-back,
         no synchronisation), so the level loop captures as is.  Before capturing, the context's intermediate buffers
-        are sized for ANY later batch (tfhe_ctx_reserve up to a full slab, with the MUX buffers): the graph records
-        their addresses, the library freezes them at the first captured call, and a context that could still need
-        to grow one would have to refuse that later call (include/tfhe_hip.h, tfhe_ctx_reserve).  One un-captured
-        run fills the op-code cache and warms torch's allocator (neither may allocate during capture)."""
+        are sized for the WIDEST LEVEL of this schedule at `max_instances` circuit instances (default: the instances
+        of `wires`; pass a larger number if the same context will later run, or capture, wider batches -- the library
+        freezes the buffers at the first captured call and refuses any later call that would have to grow them until
+        release() is called; include/tfhe_hip.h, tfhe_ctx_reserve).  One un-captured run fills the op-code cache and
+        warms torch's allocator (neither may allocate during capture)."""
         torch = self.torch
-        self.ctx.reserve(1 << 30, with_mux=True)
+        C = int(max_instances or wires.shape[1])
+        widest = max(sum(3 if g[0] == "MUX" else 1 for g in lvl) for lvl in self.levels)      # a MUX item is three bootstraps
+        self.ctx.reserve(widest * C, with_mux=any(g[0] == "MUX" for lvl in self.levels for g in lvl))
         self.run(wires)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.run(wires)
+        self._captured = True
         return graph
+
+    def release(self):
+        """Call once every graph captured through this executor's context has been destroyed: un-freezes the context's
+        intermediate buffers (TFHE_OPT_FROZEN = 0) so that later, larger batches may grow them again."""
+        self.ctx.sync()
+        self.ctx.set_option("frozen", 0)
+        self._captured = False
 
     def run(self, wires, stream=None):
         """wires: int32 tensor [n_wires][C][n+1] with the input wires filled; updated in place.

@@ -135,6 +135,9 @@ struct tfhe_ctx {
     void *comb_host = nullptr;  // page-locked staging of one combined launch: [a | b | c | out][rows][n+1] + op codes
     size_t comb_host_cap = 0;
     long long comb_launches = 0, comb_requests = 0;     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
+    void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
+                                                        // reads them after the call has returned
+    bool need_sync_all = false;                         // a stream's event could not be recorded: tfhe_ctx_sync falls back to hipDeviceSynchronize
 };
 
 namespace {
@@ -236,18 +239,18 @@ bool stream_capturing(hipStream_t st)
 // means hipFree + hipMalloc: an implicit device synchronisation, illegal while `st` is being captured, and fatal for
 // a hipGraph that already recorded the old address (tfhe_ctx::frozen).  In both cases the call is refused with a
 // message that names the remedy instead of a raw HIP error or, worse, a graph replaying into freed memory.
-int grow(tfhe_ctx *c, DevBuf &b, size_t bytes, hipStream_t st, const char *what)
+int grow(tfhe_ctx *c, DevBuf &b, size_t bytes, hipStream_t st, const char *what,
+         const char *remedy = "tfhe_ctx_reserve(ctx, max_batch, with_mux)")
 {
     if (b.fits(bytes)) return TFHE_OK;
     const bool cap = stream_capturing(st);
     if (cap || c->frozen)
         return fail(TFHE_E_INVALID,
-                    "the context's %s buffer would have to grow from %zu to %zu bytes %s: call tfhe_ctx_reserve(ctx, max_batch, "
-                    "with_mux) for the largest batch BEFORE capturing%s",
+                    "the context's %s buffer would have to grow from %zu to %zu bytes %s: call %s for the largest batch BEFORE capturing%s",
                     what, b.cap, bytes,
                     cap ? "while the stream is being captured into a hipGraph (no allocation is possible there)"
                         : "but a captured hipGraph holds its current address (the context is frozen)",
-                    cap ? "" : ", or clear TFHE_OPT_FROZEN once every such graph is destroyed");
+                    remedy, cap ? "" : ", or clear TFHE_OPT_FROZEN once every such graph is destroyed");
     return b.reserve(bytes);
 }
 
@@ -255,20 +258,26 @@ int grow(tfhe_ctx *c, DevBuf &b, size_t bytes, hipStream_t st, const char *what)
 int mark_dev_stream(tfhe_ctx *c, hipStream_t st)
 {
     if (stream_capturing(st)) return TFHE_OK;             // an event record would become a node of the caller's graph
-    constexpr size_t kMaxMarks = 8;
+    // The batch this mark follows HAS been enqueued: a failure to record the mark must not be reported as a failure of the
+    // call (the caller would believe nothing ran).  It is remembered instead, and tfhe_ctx_sync / tfhe_ctx_destroy then wait
+    // for the whole device.
+    auto give_up = [&]() { (void)hipGetLastError(); c->need_sync_all = true; return TFHE_OK; };
     for (auto &m : c->dev_marks)
-        if (m.key == st) { HIP_TRY(hipEventRecord(m.ev, st)); return TFHE_OK; }
+        if (m.key == st) return hipEventRecord(m.ev, st) == hipSuccess ? TFHE_OK : give_up();
+    constexpr size_t kSoftMarks = 8;
     tfhe_ctx::DevStreamMark m{st, nullptr};
-    if (c->dev_marks.size() >= kMaxMarks) {               // recycle the oldest mark once its work is done
-        m.ev = c->dev_marks.front().ev;
-        HIP_TRY(hipEventSynchronize(m.ev));
-        c->dev_marks.erase(c->dev_marks.begin());
-    } else {
-        HIP_TRY(hipEventCreateWithFlags(&m.ev, hipEventDisableTiming));
+    if (c->dev_marks.size() >= kSoftMarks) {              // recycle a mark whose work is already done -- never wait for one here:
+        for (size_t i = 0; i < c->dev_marks.size(); i++)  // this is an enqueue-only call holding the context mutex
+            if (hipEventQuery(c->dev_marks[i].ev) == hipSuccess) {
+                m.ev = c->dev_marks[i].ev;
+                c->dev_marks.erase(c->dev_marks.begin() + (long)i);
+                break;
+            }
+        (void)hipGetLastError();                          // hipErrorNotReady of the queries
     }
+    if (!m.ev && hipEventCreateWithFlags(&m.ev, hipEventDisableTiming) != hipSuccess) return give_up();     // otherwise the list grows
     c->dev_marks.push_back(m);
-    HIP_TRY(hipEventRecord(m.ev, st));
-    return TFHE_OK;
+    return hipEventRecord(m.ev, st) == hipSuccess ? TFHE_OK : give_up();
 }
 
 int timing_begin(tfhe_ctx *c, int which, hipStream_t st, hipEvent_t *stop)
@@ -616,6 +625,21 @@ int bootstrap_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, in
 //   other ext:       one launch per CMUX step over (item, component) pairs, accumulators double-buffered in global memory
 //                    (a functional path for the experimental sets), in chunks of items so that the buffers have a
 //                    fixed size whatever the batch.
+// Scratch of the extended-table bootstrap for batches of up to `items`: polyExtendFactor 2 runs the persistent kernel over the
+// ordinary slabs; the other factors keep two sets of ext accumulators and the mod-switched samples of one chunk.
+int reserve_extended_scratch(tfhe_ctx *c, int items, int ext, hipStream_t st)
+{
+    if (ext == 2) return reserve_scratch(c, items, false, st);
+    const int chunk = launch_items(c), Bc = items < chunk ? items : chunk;
+    const size_t accw = (size_t)ext * Bc * 2 * 2048, n1 = (size_t)c->P.n + 1;
+    static const char *kRemedy = "tfhe_ctx_reserve_extended(ctx, max_batch, ext)";
+    int rc;
+    if ((rc = grow(c, c->s_t2, 2 * accw * sizeof(uint32_t), st, "extended accumulator", kRemedy)) ||
+        (rc = grow(c, c->s_t3, (size_t)Bc * n1 * sizeof(uint32_t), st, "mod-switched sample", kRemedy))) return rc;
+    // the final sample extract + key switch runs on the accumulators themselves; its one-hot matrix is sized by reserve_scratch
+    return reserve_scratch(c, Bc, false, st);
+}
+
 int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_lut, int lut_per_item, int ext,
                               uint32_t *d_out, int B, hipStream_t st)
 {
@@ -649,8 +673,7 @@ int bootstrap_extended_device(tfhe_ctx *c, const uint32_t *d_in, const uint32_t 
     const int chunk = launch_items(c);                       // items per pass: the accumulators are 2 * ext * chunk TRLWE samples
     const int Bc = B < chunk ? B : chunk;
     const size_t accw = (size_t)ext * Bc * 2 * N;
-    if ((rc = grow(c, c->s_t2, 2 * accw * sizeof(uint32_t), st, "extended accumulator")) ||
-        (rc = grow(c, c->s_t3, (size_t)Bc * n1 * sizeof(uint32_t), st, "mod-switched sample"))) return rc;
+    if ((rc = reserve_extended_scratch(c, B, ext, st))) return rc;
     uint32_t *acc[2] = {c->s_t2.as<uint32_t>(), c->s_t2.as<uint32_t>() + accw};
     for (int base = 0; base < B; base += chunk) {
         const int S = B - base < chunk ? B - base : chunk;
@@ -773,6 +796,7 @@ int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
     const size_t need = planes * plane + total;
     if (need > c->comb_host_cap) {
         if (c->comb_host) (void)hipHostFree(c->comb_host);
+    for (void *h : c->hdr_host) if (h) (void)hipHostFree(h);
         c->comb_host = nullptr; c->comb_host_cap = 0;
         const size_t cap = need < ((size_t)1 << 22) ? ((size_t)1 << 22) : need + need / 2;
         hipError_t e = hipHostMalloc(&c->comb_host, cap, hipHostMallocDefault);
@@ -968,6 +992,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &m : c->dev_marks) { (void)hipEventSynchronize(m.ev); (void)hipEventDestroy(m.ev); }      // "_dev" work on caller streams
+    if (c->need_sync_all) (void)hipDeviceSynchronize();
     c->dev_marks.clear();
     for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->status, &c->s_plan, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
                       &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3, &c->kskB, &c->s_onehot})
@@ -1000,6 +1025,10 @@ int tfhe_ctx_sync(tfhe_ctx *c)
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (auto &m : c->dev_marks) HIP_TRY(hipEventSynchronize(m.ev));
+    if (c->need_sync_all) {                                  // some stream's mark could not be recorded (mark_dev_stream)
+        HIP_TRY(hipDeviceSynchronize());
+        c->need_sync_all = false;
+    }
     return check_status(c);
 }
 
@@ -1047,6 +1076,17 @@ int tfhe_ctx_reserve(tfhe_ctx *c, int max_batch, int with_mux)
     if (max_batch < 0) return fail(TFHE_E_INVALID, "bad batch size");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     return reserve_scratch(c, max_batch, with_mux != 0, c->stream);
+}
+
+int tfhe_ctx_reserve_extended(tfhe_ctx *c, int max_batch, int ext)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (max_batch < 0) return fail(TFHE_E_INVALID, "bad batch size");
+    if (c->shape != kShapeN2048_L1_B22) return fail(TFHE_E_INVALID, "extended lookup tables need the N = 2048 parameter shape");
+    if (ext < 1 || ext > 16) return fail(TFHE_E_INVALID, "polyExtendFactor %d out of range (1..16)", ext);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    return reserve_extended_scratch(c, max_batch, ext, c->stream);
 }
 
 int tfhe_load_bsk_fourier(tfhe_ctx *c, const double *bsk)
@@ -1257,10 +1297,15 @@ int tfhe_key_export_dev(tfhe_ctx *c, int which, void *d_dst, void *stream)
     if (!d_dst || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (which == 0 ? !c->have_bsk : !c->have_ksk) return fail(TFHE_E_NOKEY, "key not loaded");
-    const KeyBlobHeader h = make_header(c, which);
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(d_dst, &h, sizeof h, hipMemcpyHostToDevice, st));          // pageable source: copied before the call returns
-    HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_dst) + sizeof h, which == 0 ? c->bsk.p : c->ksk.p, h.payload_bytes,
+    if (stream_capturing(st)) return fail(TFHE_E_INVALID, "tfhe_key_export_dev on a stream that is being captured into a hipGraph");
+    // the header travels from a context-owned page-locked buffer (one per key): an asynchronous copy may read its source
+    // after this call has returned, which a stack object does not survive
+    if (!c->hdr_host[which]) HIP_TRY(hipHostMalloc(&c->hdr_host[which], sizeof(KeyBlobHeader), hipHostMallocDefault));
+    KeyBlobHeader *h = static_cast<KeyBlobHeader *>(c->hdr_host[which]);
+    *h = make_header(c, which);
+    HIP_TRY(hipMemcpyAsync(d_dst, h, sizeof *h, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(static_cast<char *>(d_dst) + sizeof *h, which == 0 ? c->bsk.p : c->ksk.p, h->payload_bytes,
                            hipMemcpyDeviceToDevice, st));
     return TFHE_OK;
 }
@@ -1272,6 +1317,8 @@ int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, size_t bytes,
     if (!d_src || which < 0 || which > 1) return fail(TFHE_E_INVALID, "bad argument");
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     hipStream_t st = (hipStream_t)stream;
+    if (stream_capturing(st))
+        return fail(TFHE_E_INVALID, "tfhe_key_import_dev on a stream that is being captured into a hipGraph (the header is checked on the host)");
     KeyBlobHeader h{};
     if (bytes < sizeof h) return fail(TFHE_E_INVALID, "key blob of %zu bytes is shorter than its header", bytes);
     HIP_TRY(hipMemcpyAsync(&h, d_src, sizeof h, hipMemcpyDeviceToHost, st));           // the one synchronisation of an import:
@@ -1340,13 +1387,16 @@ int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, doubl
     int rc = check_ctx(c);                                          \
     if (rc) return rc;                                              \
     std::lock_guard<std::recursive_mutex> lk(c->mu);                \
-    hipStream_t st = pick(c, stream);                               \
-    if (stream_capturing(st)) c->frozen = true      /* the graph will hold the intermediate buffers' addresses */
+    hipStream_t st = pick(c, stream)
 // ... and behind the enqueued work the stream's event is re-recorded (tfhe_ctx_sync / tfhe_ctx_destroy wait on it)
+// A call that HAS enqueued work on a capturing stream freezes the context: the graph now holds the intermediate buffers'
+// addresses.  (Not before: a call rejected for its arguments or for a missing key must not freeze anything.)
 #define DEV_RETURN(expr)                                            \
     do {                                                            \
         rc = (expr);                                                \
-        return rc ? rc : mark_dev_stream(c, st);                    \
+        if (rc) return rc;                                          \
+        if (stream_capturing(st)) c->frozen = true;                 \
+        return mark_dev_stream(c, st);                              \
     } while (0)
 
 int tfhe_blind_rotate_batch_dev(tfhe_ctx *c, const uint32_t *d_in, const uint32_t *d_tv, int tv_per_item,

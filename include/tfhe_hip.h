@@ -11,8 +11,9 @@
  *     TFHE_E_* code and never throws; tfhe_last_error() gives the message.  The
  *     reference panics on every error on this path; the cgo shim turns rc != 0 into
  *     panic() to keep that behaviour.
- *   - a context belongs to ONE GPU and is single-submitter, like evaluator.Evaluator
- *     (evaluator.go:14-24: "not goroutine-safe"); use one context per GPU/goroutine.
+ *   - a context belongs to ONE GPU.  Its calls are thread-safe and take effect one after the other, like calls on one
+ *     evaluator.Evaluator (evaluator.go:14-24) -- except tfhe_gate_batch, whose concurrent callers are COMBINED into
+ *     one launch (see there): many threads issuing scalar gates on one context is a supported, fast pattern.
  *   - keys are copied at load time and are immutable afterwards.
  *   - outputs are caller-owned (the *Assign style of the reference).
  *   - "_dev" variants take DEVICE pointers and a hipStream_t (as void*; NULL = HIP's
@@ -99,6 +100,9 @@ int tfhe_ctx_sync(tfhe_ctx *ctx);
  * call of any kind that needs larger buffers returns TFHE_E_INVALID rather than freeing memory a graph replay would
  * touch.  Clear TFHE_OPT_FROZEN after destroying the graphs to allow growth again. */
 int tfhe_ctx_reserve(tfhe_ctx *ctx, int max_batch, int with_mux);
+/* The same for tfhe_bootstrap_extended_batch_dev with polyExtendFactor ext (N = 2048 shape): the factors other than 2 keep
+ * two sets of ext accumulators and the mod-switched samples of one chunk of the batch, which tfhe_ctx_reserve does not size. */
+int tfhe_ctx_reserve_extended(tfhe_ctx *ctx, int max_batch, int ext);
 
 /* Per-context options.  Kernel dispatch is a function of the parameters and the batch size only; these exist for
  * measurements (tools/) and tests, and are deliberately NOT read from the environment: a service must not change

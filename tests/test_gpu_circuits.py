@@ -66,6 +66,8 @@ def test_adder_reference_form_40_gates_x256_128bit(oracle, keys128, ck128, pkg):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(wt2, wt)
+    del graph
+    ex.release()                                             # the context is shared with later, larger batches
 
 
 def test_adder_8bit_x256_128bit(oracle, keys128, ck128, pkg):
@@ -191,6 +193,8 @@ def test_mux_stream_captured_into_a_graph(oracle, keys128, ck128, pkg):
         torch.cuda.synchronize()
         assert np.array_equal(bufs[3].cpu().numpy().view(np.uint32), ck128.ctx.gate_batch(ops, a, b, c))
     ck128.ctx.sync()
+    del graph
+    ck128.ctx.set_option("frozen", 0)                        # the graph is gone; later tests on this context run larger batches
 
 
 def test_dev_path_reports_bad_op_codes_at_sync(ck128, keys128, pkg):
@@ -268,11 +272,8 @@ def test_growth_during_or_after_capture_is_refused_not_undefined(pkg, keys_small
         with torch.cuda.graph(graph, stream=side):
             ctx.gate_batch_dev("NAND", a, b, None, out, side)
     torch.cuda.synchronize()
-    assert ctx.get_option("frozen") == 1               # a call was issued on a capturing stream
-    with pytest.raises(pkg.TfheError, match="frozen"):
-        ctx.gate_batch_dev("NAND", a, b, None, out)    # un-captured, but would re-allocate what a graph may hold
-    ctx.set_option("frozen", 0)
-    ctx.gate_batch_dev("NAND", a, b, None, out)        # grows now
+    assert ctx.get_option("frozen") == 0               # the refused call enqueued nothing: no graph holds any address
+    ctx.gate_batch_dev("NAND", a, b, None, out)        # un-captured: grows
     ctx.sync()
     want = ~(np.array([0, 1] * 32, bool) & np.array([1, 1] * 32, bool))
     assert np.array_equal(k.dec(out.cpu().numpy().view(np.uint32)), want)
@@ -287,10 +288,50 @@ def test_growth_during_or_after_capture_is_refused_not_undefined(pkg, keys_small
     assert np.array_equal(k.dec(out.cpu().numpy().view(np.uint32)), want)
     ctx.gate_batch_dev("AND", a[:8].contiguous(), b[:8].contiguous(), None, out[:8])
     ctx.sync()
+    assert ctx.get_option("frozen") == 1               # a call WAS captured: the graph holds the buffers' addresses
+    big = torch.cat([a, a, a])
     with pytest.raises(pkg.TfheError, match="frozen"):
-        big = torch.cat([a, a, a])
         ctx.gate_batch_dev("NAND", big, torch.cat([b, b, b]), None, torch.zeros_like(big))
+    # a captured call with bad arguments is refused without side effects on a fresh context either
     del graph
+    ctx.set_option("frozen", 0)                        # the graph is gone: growth is allowed again
+    big_out = torch.zeros_like(big)
+    ctx.gate_batch_dev("NAND", big, torch.cat([b, b, b]), None, big_out)
+    ctx.sync()
+    assert np.array_equal(k.dec(big_out.cpu().numpy().view(np.uint32)), np.concatenate([want] * 3))
+    ck.close()
+
+
+def test_executor_capture_reserves_for_its_widest_level_and_release_unfreezes(pkg, keys_small):
+    """CircuitExecutor.capture sizes the context for the widest level of ITS schedule (not for a full 65,536-item slab with MUX
+    buffers, ~1 GB, as it did until round 4); release() clears the frozen flag once the graphs are gone."""
+    import torch
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor
+    k = keys_small
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    bits, C = 2, 4
+    levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+    n1 = k.p.n + 1
+    wires = np.zeros((n_wires, C, n1), np.uint32)
+    av, bv = np.array([0, 1, 2, 3]), np.array([3, 3, 1, 2])
+    for i in range(bits):
+        wires[i] = k.enc((av >> i) & 1)
+        wires[bits + i] = k.enc((bv >> i) & 1)
+    wires[adder_constant_wire(bits)] = pkg.gates.Constant(False, k.p)
+    wt = torch.from_numpy(wires.view(np.int32)).cuda()
+    ex = CircuitExecutor(ck.ctx, levels, n_wires)
+    free0 = torch.cuda.mem_get_info()[0]
+    graph = ex.capture(wt)
+    assert free0 - torch.cuda.mem_get_info()[0] < 256 << 20, "capture() reserved far more than this circuit's widest level needs"
+    graph.replay()
+    torch.cuda.synchronize()
+    res = wt.cpu().numpy().view(np.uint32)
+    got = sum(k.dec(res[w]).astype(np.int64) << i for i, w in enumerate(sums)) + (k.dec(res[cout]).astype(np.int64) << bits)
+    assert np.array_equal(got, av + bv)
+    assert ck.ctx.get_option("frozen") == 1
+    del graph
+    ex.release()
+    assert ck.ctx.get_option("frozen") == 0
     ck.close()
 
 

@@ -148,3 +148,46 @@ def test_extended_lut_full_dimension_uint6(oracle, pkg):
 def test_extended_lut_rejected_on_other_shapes(oracle, pkg, ck_small, keys_small):
     with pytest.raises(pkg.TfheError):
         ck_small.ctx.bootstrap_extended_batch(np.zeros((1, keys_small.p.n + 1), np.uint32), np.zeros((2, 2, 1024), np.uint32))
+
+
+def test_extended_lut_captures_after_reserve_extended(oracle, pkg):
+    # polyExtendFactor 4 keeps the launch-per-step path, whose accumulators tfhe_ctx_reserve does not size: without
+    # tfhe_ctx_reserve_extended a captured call is refused with a message that names it; with it the call captures, replays
+    # and reproduces the un-captured result word for word
+    import torch
+    from go_tfhe_amd.lut import Generator
+    ks = KeySet(oracle, "uint5", 0x7F4E0059, n_override=16, torus=False)
+    modulus, ext, B = 128, 4, 24
+    gen = Generator(ks.p, modulus, polyExtendFactor=ext)
+    lut = gen.GenLookUpTableExtended(lambda x: (x + 9) % modulus)
+    rs = np.random.RandomState(59)
+    cts = _encrypt(oracle, ks, rs.randint(0, modulus, B), modulus)
+    d_cts = torch.from_numpy(cts.view(np.int32)).cuda()
+    d_lut = torch.from_numpy(lut.view(np.int32)).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+
+    ck = _ctx(pkg, ks)
+    ck.ctx.reserve(B)                                        # the wrong reserve for this entry point
+    d_out = torch.zeros_like(d_cts)
+    with pytest.raises(pkg.TfheError, match="tfhe_ctx_reserve_extended"):
+        with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=side):
+            ck.ctx.bootstrap_extended_batch_dev(d_cts, d_lut, d_out, side)
+    torch.cuda.synchronize()
+    assert ck.ctx.get_option("frozen") == 0                  # the refused call froze nothing
+    ck.ctx.bootstrap_extended_batch_dev(d_cts, d_lut, d_out)
+    ck.ctx.sync()
+    want = d_out.cpu().numpy().copy()
+    ck.close()
+
+    ck = _ctx(pkg, ks)
+    ck.ctx.reserve_extended(B, ext)
+    d_out.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        ck.ctx.bootstrap_extended_batch_dev(d_cts, d_lut, d_out, side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    del graph
+    ck.close()

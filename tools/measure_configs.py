@@ -40,6 +40,7 @@ for tag, fold in (("reference40", False), ("folded37", True)):
             "gates": G, "levels": len(lv), "widths": [len(l) for l in lv], "seconds": dt, "gates_per_s": G / dt,
             "adds_per_s": 256 / dt, "graph_replay_seconds": dtg, "graph_gates_per_s": G / dtg}
         del graph
+        ex.release()
 # config 5 (one-GPU slice): mixed AND/OR/XOR/MUX stream, 65536 gates
 B = 65536
 ops = torch.from_numpy(np.array([1, 2, 3, 10], np.uint8)[rs.randint(0, 4, B)]).cuda()
