@@ -395,9 +395,9 @@ def extra_configs(pkg, key, ck, dev, ceil=None):
 def keyswitch_hbm_record(p, B, ks_ms, ceil):
     """The one kernel of the path that HBM binds: the Uint5 key switch (k_keyswitch_wide<6>, trgsw/keyswitch.go:10-37) walks a
     1.66 GB table -- six times the Infinity Cache -- exactly once per launch.  Compulsory bytes = the packed table (the all-zero k = 0
-    rows dropped, rows padded to 16 B: [N][t][base-1][n1p] words) + the extracted accumulators in + the LWE samples out; measured
+    rows dropped, rows padded to whole 128-byte lines: [N][t][base-1][n1p] words) + the extracted accumulators in + the LWE samples out; measured
     bytes from the committed rocprofv3 PMC pass of the same launch."""
-    n1p = (p.n + 1 + 3) // 4 * 4
+    n1p = (p.n + 1 + 31) // 32 * 32
     table = p.N * p.t * (p.base - 1) * n1p * 4
     io = B * (p.N + 1) * 4 + B * (p.n + 1) * 4           # A polynomial + body word in, LWE out
     comp = table + io

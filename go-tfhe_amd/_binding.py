@@ -416,7 +416,7 @@ class Context:
                                                   blob.numel() * blob.element_size(), self._stream(stream)))
 
     OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4, "combine_max": 5, "combine_launches": 6,
-               "combine_requests": 7}
+               "combine_requests": 7, "ks_wide_ct": 8}
 
     def set_option(self, name, value):
         """tfhe_ctx_set_option: kernel-dispatch limits for measurements and tests ("quad_max", "oct_max", "ks_mfma_min";

@@ -35,7 +35,7 @@ namespace tfhe {
 //             so every key load is one fully coalesced global_load_dwordx4 per wave.
 //     Same byte count as the reference's [n][2L][2][N] float64 (68,812,800 B at 128-bit).
 //
-// Key-switching key (packed): uint32 ksk[N][t][base-1][n1p], n1p = (n+1) rounded up to 4 words.
+// Key-switching key (packed): uint32 ksk[N][t][base-1][n1p], n1p = (n+1) rounded up to 32 words (whole 128-byte lines).
 //     The k = 0 rows of the reference table are all-zero and never read (keyswitch.go:30),
 //     so they are not stored; rows are padded so each lane can fetch 16 B aligned.
 // ------------------------------------------------------------------------------------
@@ -712,11 +712,16 @@ __global__ __launch_bounds__(64) void k_keyswitch_pair(KeySwitchArgs A, int B, i
 // ds_read_b32 at a scalar-selected row.  Every key row slice crosses L2 once per 256 ciphertexts.
 // grid = ceil(B/256) * ceil((n+1)/64) * ranges workgroups (1-D, rounded up to the 8 XCDs); partial sums are
 // combined by atomics into the output k_ks_init prepared.  (keyswitch.go:10-37, trlwe_ops.go:10-21)
-template <int BB>
+template <int BB, int CT = 64>
 __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, int ranges, int ct_tiles, int col_blocks)
 {
-    constexpr int base = 1 << BB, C = 64, CQ = C / 4;            // one column per lane (two per lane: 256 VGPRs,
-                                                                 // one wave per SIMD, 0.82 vs 0.61 ms at Uint5 x 512)
+    // CT = ciphertexts per wave (64 or 128): a workgroup's staged key rows serve 4 CT ciphertexts.  With CT = 128 every key
+    // row crosses L2 / the fabric once per 512 ciphertexts instead of once per 256 -- at Uint5 x 512 the two 256-ciphertext
+    // tiles of CT = 64 fetch 2.65 GB for a 1.66 GB table (rocprofv3 FETCH_SIZE, profiles/r04_c_pmc_uint5_summary.txt), which is
+    // what the kernel's time follows -- and a staged tile and its barrier are amortised over twice the reads.
+    static_assert(CT == 64 || CT == 128, "ciphertexts per wave");
+    constexpr int base = 1 << BB, C = 64, CQ = C / 4, H = CT / 64;   // one column per lane (two per lane: 256 VGPRs,
+                                                                     // one wave per SIMD, 0.82 vs 0.61 ms at Uint5 x 512)
     constexpr int Q = (base - 1) * CQ, R = (Q + 255) / 256;      // staged uint4 per step, per thread
     __shared__ uint32_t rowbuf[2][base][C];                      // [buffer][digit][column]; digit 0 = zeros
     const int tid = threadIdx.x, lane = tid & 63;
@@ -734,10 +739,10 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
     }
     // coefficient range cr of `ranges` (any number, not only a divisor of N: the launcher sizes the grid to fill whole rounds of
     // resident workgroups -- Uint5 x 512: 1,088 workgroups on 768 slots took two rounds, 748 take one)
-    if (tile_x * 256 >= B || tile_cr >= col_blocks * ranges) return;      // whole workgroup (the barriers below are workgroup-wide)
+    if (tile_x * 4 * CT >= B || tile_cr >= col_blocks * ranges) return;      // whole workgroup (the barriers below are workgroup-wide)
     const int cr = tile_cr / col_blocks;
     const int i0 = (int)((long long)cr * N / ranges), IC = (int)((long long)(cr + 1) * N / ranges) - i0;
-    const int b0 = tile_x * 256 + w * 64, c0 = (tile_cr % col_blocks) * C;
+    const int b0 = tile_x * 4 * CT + w * CT, c0 = (tile_cr % col_blocks) * C;
     const uint32_t prec = 1u << (32 - (1 + BB * t));
     const int wshift = 32 - BB * t;
     if (tid < C) rowbuf[0][0][tid] = rowbuf[1][0][tid] = 0u;
@@ -754,8 +759,8 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
     }
     const size_t pair_stride = (size_t)(base - 1) * A.n1p / 4;   // uint4 per (i, j) pair
     constexpr int buf_quads = base * C / 4;
-    auto digit_word = [&](int i) -> uint32_t {
-        const int b = b0 + lane;
+    auto digit_word = [&](int i, int half) -> uint32_t {         // lane b holds ciphertext b0 + 64 half + b
+        const int b = b0 + 64 * half + lane;
         if (b >= B) return 0u;
         const uint32_t *ta = A.trlwe + (size_t)b * 2 * N;
         const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];                // trlwe_ops.go:13-19
@@ -770,10 +775,12 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
     const int F = IC * t;
 #pragma unroll
     for (int r = 0; r < R; r++) g[r] = live[r] ? src[r][(F > 1 ? 1 : 0) * pair_stride] : make_uint4(0, 0, 0, 0);
-    uint32_t acc[64];
+    uint32_t acc[CT];
 #pragma unroll
-    for (int b = 0; b < 64; b++) acc[b] = 0u;
-    uint32_t wm = digit_word(i0), wnext = IC > 1 ? digit_word(i0 + 1) : 0u;
+    for (int b = 0; b < CT; b++) acc[b] = 0u;
+    uint32_t wm[H], wnext[H];
+#pragma unroll
+    for (int hh = 0; hh < H; hh++) { wm[hh] = digit_word(i0, hh); wnext[hh] = IC > 1 ? digit_word(i0 + 1, hh) : 0u; }
     __syncthreads();
     int j = 0, ii = 0;
     for (int f = 0; f < F; f++) {
@@ -790,22 +797,28 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
         // lane b computes, once per step, the byte offset of the row ciphertext b selects; the loop reads it out
         // with one v_readlane per ciphertext (extracting the digit per ciphertext in scalar code instead cost
         // 0.77 vs 0.61 ms at Uint5 x 512)
-        const int sel = (int)((wm >> (BB * (t - 1 - j))) & (uint32_t)(base - 1)) * (int)(C * sizeof(uint32_t));
         const char *tile = reinterpret_cast<const char *>(&rowbuf[cur][0][lane]);
 #pragma unroll
-        for (int b = 0; b < 64; b++)
-            acc[b] -= *reinterpret_cast<const uint32_t *>(tile + __builtin_amdgcn_readlane(sel, b));
+        for (int hh = 0; hh < H; hh++) {
+            const int sel = (int)((wm[hh] >> (BB * (t - 1 - j))) & (uint32_t)(base - 1)) * (int)(C * sizeof(uint32_t));
+#pragma unroll
+            for (int b = 0; b < 64; b++)
+                acc[64 * hh + b] -= *reinterpret_cast<const uint32_t *>(tile + __builtin_amdgcn_readlane(sel, b));
+        }
         __syncthreads();
         if (++j == t) {
             j = 0; ii++;
-            wm = wnext;
-            wnext = ii + 1 < IC ? digit_word(i0 + ii + 1) : 0u;
+#pragma unroll
+            for (int hh = 0; hh < H; hh++) {
+                wm[hh] = wnext[hh];
+                wnext[hh] = ii + 1 < IC ? digit_word(i0 + ii + 1, hh) : 0u;
+            }
         }
     }
     const int col = c0 + lane;
     if (col <= A.n) {
 #pragma unroll
-        for (int b = 0; b < 64; b++) {
+        for (int b = 0; b < CT; b++) {
             if (b0 + b >= B) break;
             if (acc[b]) atomicAdd(A.out + (size_t)(b0 + b) * (A.n + 1) + col, acc[b]);
         }

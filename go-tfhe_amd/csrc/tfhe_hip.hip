@@ -87,7 +87,10 @@ struct tfhe_ctx {
     int device = 0;
     int shape = 0;              // tfhe::Shape (launch_blind_rotate.hpp)
     uint32_t offset = 0;        // cloudkey.go:60-71
-    int n1p = 0;                // padded LWE row length of the packed KSK
+    int n1p = 0;                // row length of the packed KSK in words: n + 1 rounded up to 32 words = whole 128-byte lines, so
+                                // that the 256-byte column slices the tiled key switches read are line-aligned in EVERY row (at
+                                // Uint5, 1,072-word rows put every other row's slices across three lines instead of two and each
+                                // XCD fetched the shared line again: 2.3 GB per launch for a 1.66 GB table, round 4)
     int num_cus = 256;          // hipDeviceProp_t.multiProcessorCount
     // host-pointer batches longer than one slab: transfers of slab s+1 / s-1 overlap the kernels of slab s
     hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
@@ -116,6 +119,7 @@ struct tfhe_ctx {
     DevBuf kskB;                // byte-column copy of the key-switching key for the MFMA form (keyswitch_mfma.hpp; base-4 sets)
     DevBuf s_onehot;            // its per-launch one-hot digit matrix
     int ks_mfma_min = 0;        // batches of at least this many ciphertexts use it
+    int ks_wide_ct = 0;         // k_keyswitch_wide: ciphertexts per wave, 0 = by batch size (TFHE_OPT_KS_WIDE_CT)
     DevBuf bskq, twq;           // four-wave layout of the key + its twiddles (N = 1024 shapes, kernels_quad.hpp)
     bool have_bsk = false, have_ksk = false;
     // staging (grow-only)
@@ -463,13 +467,18 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     }
     // larger bases (Uint sets), batches that fill at least one wave of ciphertexts: column-sliced tiles
     if (c->P.basebit >= 4 && c->P.basebit <= 7 && B >= 64) {
-        const int ct_tiles = (B + 255) / 256, col_blocks = (c->P.n + 1 + 63) / 64;
+        // 256 ciphertexts per workgroup (64 per wave).  The form with 128 per wave (a key row crosses L2 once per 512 ciphertexts)
+        // needs 296 registers, i.e. one wave per SIMD: 0.92 vs 0.57 ms at Uint5 x 512 (profiles/r04_e_keyswitch_hbm.txt); it stays
+        // selectable for measurements (TFHE_OPT_KS_WIDE_CT = 128).
+        const bool big = c->ks_wide_ct == 128 && c->P.basebit <= 6;      // measured slower (one wave per SIMD): only on request
+        const int per_wg = big ? 512 : 256;
+        const int ct_tiles = (B + per_wg - 1) / per_wg, col_blocks = (c->P.n + 1 + 63) / 64;
         // coefficient ranges: as many as fill k whole rounds of the resident workgroups (three per CU by registers, two at
-        // base 128 by LDS) -- the kernel's time goes with rounds x coefficients per workgroup, so a grid that ends in a
-        // part-filled round wastes the difference (Uint5 x 512: 1,088 workgroups on 768 slots 0.60 ms, 3,060 on 4 x 768
-        // 0.50 ms; profiles/r03_k_keyswitch_rounds.txt).  k = 1...8 with at least 20 coefficients per workgroup: the best
-        // fill, the larger k on a tie (shorter workgroups even out the tail).
-        const int slots = (c->P.basebit >= 7 ? 2 : 3) * c->num_cus, units = ct_tiles * col_blocks;
+        // base 128 by LDS and with 128 ciphertexts per wave by registers) -- the kernel's time goes with rounds x coefficients
+        // per workgroup, so a grid that ends in a part-filled round wastes the difference (Uint5 x 512: 1,088 workgroups on 768
+        // slots 0.60 ms, 3,060 on 4 x 768 0.50 ms; profiles/r03_k_keyswitch_rounds.txt).  k = 1...8 with at least 20
+        // coefficients per workgroup: the best fill, the larger k on a tie (shorter workgroups even out the tail).
+        const int slots = (big ? 1 : c->P.basebit >= 7 ? 2 : 3) * c->num_cus, units = ct_tiles * col_blocks;
         int ranges = 1;
         double best_fill = 0.0;
         for (int k = 1; k <= 8; k++) {
@@ -483,12 +492,16 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         const size_t tot = (size_t)B * (c->P.n + 1);
         hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
         const dim3 g((unsigned)((col_blocks * ranges + 7) / 8 * 8 * ct_tiles));                // XCD decode: see the kernel
+#define KSW(BBv)                                                                                                            \
+        if (big) hipLaunchKernelGGL((k_keyswitch_wide<BBv, 128>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks);     \
+        else hipLaunchKernelGGL((k_keyswitch_wide<BBv, 64>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks)
         switch (c->P.basebit) {
-        case 4: hipLaunchKernelGGL((k_keyswitch_wide<4>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
-        case 5: hipLaunchKernelGGL((k_keyswitch_wide<5>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
-        case 6: hipLaunchKernelGGL((k_keyswitch_wide<6>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
-        default: hipLaunchKernelGGL((k_keyswitch_wide<7>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
+        case 4: KSW(4); break;
+        case 5: KSW(5); break;
+        case 6: KSW(6); break;
+        default: hipLaunchKernelGGL((k_keyswitch_wide<7, 64>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
         }
+#undef KSW
         HIP_TRY(hipGetLastError());
         return timing_end(c, 1, st, stop);
     }
@@ -951,7 +964,7 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     } guard{new tfhe_ctx};
     tfhe_ctx *c = guard.c;
     c->P = *P; c->device = device_id; c->shape = shape;
-    c->n1p = (P->n + 1 + 3) & ~3;
+    c->n1p = (P->n + 1 + 31) & ~31;      // whole 128-byte lines: see tfhe_ctx::n1p
     for (int i = 0; i < P->L; i++) c->offset += (1u << (P->Bgbit - 1)) * (1u << (32 - (i + 1) * P->Bgbit));
     {
         hipDeviceProp_t prop;
@@ -1049,6 +1062,10 @@ int tfhe_ctx_set_option(tfhe_ctx *c, int option, int value)
         return TFHE_OK;
     case TFHE_OPT_FROZEN: c->frozen = value != 0; return TFHE_OK;
     case TFHE_OPT_COMBINE_MAX: c->combine_max = value < 0 ? launch_items(c) : value; return TFHE_OK;
+    case TFHE_OPT_KS_WIDE_CT:
+        if (value > 0 && value != 64 && value != 128) return fail(TFHE_E_INVALID, "TFHE_OPT_KS_WIDE_CT is 64, 128 or 0 / -1 (by batch size)");
+        c->ks_wide_ct = value < 0 ? 0 : value;
+        return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);
     }
 }
@@ -1063,6 +1080,7 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_KS_MFMA_MIN: *value = c->ks_mfma_min; return TFHE_OK;
     case TFHE_OPT_FROZEN: *value = c->frozen ? 1 : 0; return TFHE_OK;
     case TFHE_OPT_COMBINE_MAX: *value = c->combine_max; return TFHE_OK;
+    case TFHE_OPT_KS_WIDE_CT: *value = c->ks_wide_ct; return TFHE_OK;
     case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)c->comb_launches; return TFHE_OK;
     case TFHE_OPT_COMBINE_REQUESTS: *value = (int)c->comb_requests; return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);

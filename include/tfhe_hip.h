@@ -118,7 +118,9 @@ enum {
     TFHE_OPT_COMBINE_MAX = 5,  /* tfhe_gate_batch calls of at most this many gates are COMBINED with concurrent callers'
                                   (see tfhe_gate_batch); default (and -1) = one launch's worth, 0 = never                  */
     TFHE_OPT_COMBINE_LAUNCHES = 6,  /* read-only: combined launches issued so far ...                                       */
-    TFHE_OPT_COMBINE_REQUESTS = 7   /* ... and the tfhe_gate_batch calls they carried                                       */
+    TFHE_OPT_COMBINE_REQUESTS = 7,  /* ... and the tfhe_gate_batch calls they carried                                       */
+    TFHE_OPT_KS_WIDE_CT = 8    /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
+                                  only: one wave per SIMD, slower)                                                         */
 };
 int tfhe_ctx_set_option(tfhe_ctx *ctx, int option, int value);
 int tfhe_ctx_get_option(tfhe_ctx *ctx, int option, int *value);

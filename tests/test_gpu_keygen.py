@@ -190,7 +190,7 @@ def test_keygen_noise_statistics(oracle, pkg):
     bskb = ck.ctx.key_export_dev(0).cpu().numpy()[64:]
     ck.close()
     # ---- key-switching key: packed rows [N*t*(base-1) + 1][n1p], row (i, j, k-1) encrypts k*s1[i]*2^(32-(j+1)*basebit) under s0
-    n1p = (p.n + 1 + 3) & ~3
+    n1p = (p.n + 1 + 31) & ~31                              # rows are whole 128-byte lines (tfhe_ctx::n1p)
     rows = ksk.reshape(-1, n1p)[:-1]                        # the last row is the all-zero padding row
     base1 = (1 << p.basebit) - 1
     assert rows.shape[0] == p.N * p.t * base1 and rows.shape[0] >= 4096
