@@ -99,6 +99,38 @@ template <int S> __device__ __forceinline__ void dft4_pretwist(cd (&x)[4], const
     x[0] = t0 + t2; x[2] = t0 - t2; x[1] = t1 + t3; x[3] = t1 - t3;
 }
 
+// Exchange 1 WITHOUT LDS.  (reg m; lane 16b + c) -> (reg b; lane 16m + c) is a 4 x 4 transpose of the four registers across
+// the wavefront's four 16-lane rows, which gfx950's two swap instructions do directly: v_permlane32_swap exchanges the upper
+// 32 lanes of one register with the lower 32 of another (the 2 x 2 block step), v_permlane16_swap the odd rows of one with the
+// even rows of another (the step inside the blocks) -- four swaps per 32-bit plane, 16 for four complex doubles, against four
+// ds_write_b128 + four ds_read_b128 and their round trip.  The eight-wave kernel's forward phase is bound by the LDS store path
+// (profiles/r04_b_oct_floor.txt): this takes a third of its exchange bytes off that path: 2.375 -> 2.20 ms per blind rotate.
+// (The other two exchanges permute lanes INSIDE a row, where a register path needs a select per 32-bit plane and stage: exchange 3 as
+// 32 v_cndmask_b32_dpp was measured, 2.18 -> 2.40 ms; they stay in LDS.)
+__device__ __forceinline__ void swap_halves32(double &a, double &b)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void swap_rows16(double &a, double &b)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void quad_row_transpose(cd (&x)[4])
+{
+    swap_halves32(x[0].re, x[2].re); swap_halves32(x[0].im, x[2].im);
+    swap_halves32(x[1].re, x[3].re); swap_halves32(x[1].im, x[3].im);
+    swap_rows16(x[0].re, x[1].re); swap_rows16(x[0].im, x[1].im);
+    swap_rows16(x[2].re, x[3].re); swap_rows16(x[2].im, x[3].im);
+}
+
 // LDS slots (16 B each, 256 per wave) of the three exchanges; (hi, mid, lo) = the lane's three base-4 digits.
 //   exchange 1: element (reg m; lane b,c,d)      at 64m + 16b + 4c + d
 //   exchange 2: element (reg m'; lane m,c,d)     at 64m + 16m' + 4((c+m')&3) + d
@@ -123,12 +155,7 @@ __device__ __forceinline__ void fft256_forward_batch(cd (&x)[NB][4], cd *sc, con
 #pragma unroll
     for (int t = 0; t < NB; t++) {
         dft4_pretwist<1>(x[t], T[1], T[2], T[3]);
-        #pragma unroll
-        for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];
-        wave_lds_order();
-        #pragma unroll
-        for (int b = 0; b < 4; b++) x[t][b] = sc[64 * q.hi + 16 * b + (q.lane & 15)];
-        wave_lds_order();
+        quad_row_transpose(x[t]);                   // exchange 1 in registers
     }
 #pragma unroll
     for (int t = 0; t < NB; t++) {
@@ -165,11 +192,7 @@ __device__ __forceinline__ void fft256_forward_batch_pipe(cd (&x)[NB][4], cd *sc
 {
     auto xchg = [&](int lvl, int t) {
         if (lvl == 1) {
-#pragma unroll
-            for (int m = 0; m < 4; m++) sc[64 * m + q.lane] = x[t][m];
-            wave_lds_order();
-#pragma unroll
-            for (int b = 0; b < 4; b++) x[t][b] = sc[64 * q.hi + 16 * b + (q.lane & 15)];
+            quad_row_transpose(x[t]);               // exchange 1 in registers
         } else if (lvl == 2) {
 #pragma unroll
             for (int mp = 0; mp < 4; mp++) sc[64 * q.hi + 16 * mp + 4 * ((q.mid + mp) & 3) + q.lo] = x[t][mp];
@@ -244,12 +267,7 @@ __device__ __forceinline__ void fft256_inverse(cd (&x)[4], cd *sc, const cd *__r
     dft4<-1>(x);
 #pragma unroll
     for (int b = 1; b < 4; b++) x[b] = cmulc(x[b], tw.w[0][b - 1]);
-    #pragma unroll
-    for (int b = 0; b < 4; b++) sc[64 * q.hi + 16 * b + (q.lane & 15)] = x[b];
-    wave_lds_order();
-    #pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = sc[64 * m + q.lane];
-    wave_lds_order();
+    quad_row_transpose(x);                          // exchange 1 backwards: the transpose is its own inverse
     dft4<-1>(x);
 #pragma unroll
     for (int a = 0; a < 4; a++) x[a] = cmul(x[a], T[4 + a]);
