@@ -110,12 +110,12 @@ def balance_levels(levels, width):
 
 
 def launch_cost_ms(bootstraps, full=1024):
-    """Measured time of one level of `bootstraps` gate bootstraps on one MI355X (blind rotate + key switch, 128-bit set,
-    profiles/r03_n_phase_priorities.txt, one box): a step function of the launch shape -- up to 256 (one bootstrap per CU)
-    run the eight-wave kernel, up to 512 the two-wave kernel with two bootstraps per four-wave workgroup (one per CU), then
-    three two-wave workgroups per CU, then two four-wave workgroups per CU (both with phase priorities); longer levels are
-    full launches plus a tail."""
-    steps = ((256, 2.60), (512, 4.05), (768, 4.95), (1024, 5.78))
+    """Measured time of one level of `bootstraps` gate bootstraps on one MI355X (blind rotate + key switch, 128-bit set; round 4:
+    profiles/r04_b_oct_floor.txt, r04_f_fold8_ab.txt, one box each): a step function of the launch shape -- up to 256 (one
+    bootstrap per CU) run the eight-wave kernel, up to 512 the two-wave kernel with two bootstraps per four-wave workgroup (one per
+    CU), then three two-wave workgroups per CU, then two four-wave workgroups per CU (both with phase priorities); longer levels
+    are full launches plus a tail."""
+    steps = ((256, 2.30), (512, 3.98), (768, 4.61), (1024, 5.50))
     n_full, rem = divmod(int(bootstraps), full)
     t = n_full * steps[-1][1]
     if rem:
