@@ -2,9 +2,9 @@
 
 The reference's CloudKey holds {DecompositionOffset, BlindRotateTestvec, KeySwitchingKey,
 BootstrappingKey} as Go pointer graphs.  Here the same four things live on one GPU inside a
-Context: offset and gate test vector are derived from the parameters at context creation, the
-two keys are uploaded once from flat arrays (what a cgo shim would flatten them to).
-Key GENERATION stays with the caller (it needs the secret key).
+Context: offset and gate test vector are derived from the parameters at context creation; the
+two keys are either uploaded once from flat arrays (what a cgo shim would flatten them to) or
+generated on the GPU from the two binary secret keys (NewCloudKey below).
 """
 from ._binding import Context
 
