@@ -512,9 +512,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, group = None, None
-    backend = os.environ.get("TFHE_BENCH_BACKEND", "nccl")      # "gloo" only for single-GPU dry runs of the N>1 path
+    # data-path backend to ask for: RCCL, unless this is a dry run of the N > 1 path with the ranks sharing one GPU (RCCL refuses
+    # two ranks on one device).  TFHE_BENCH_BACKEND overrides -- "nccl" on a shared GPU exercises the fallback handshake for real.
+    backend = os.environ.get("TFHE_BENCH_BACKEND") or ("gloo" if share else "nccl")
     if world > 1 or args.mode == "sharded":
-        dist, group, backend = init_distributed(rank, world, dev, backend if not share else "gloo")
+        dist, group, backend = init_distributed(rank, world, dev, backend)
 
     _bar = []
 
