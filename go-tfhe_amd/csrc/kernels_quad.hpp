@@ -526,9 +526,16 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
     const int item = A.first + blockIdx.x;
     if (!gate_item_live(A, item)) return;
     const bool bad_op = gate_prep_modswitch(A, item, tid, 512, N, abarL, &btL);
-    const cd *T = A.twq + (size_t)h * kTwQuadHalf;
+    const cd *Tg = A.twq + (size_t)h * kTwQuadHalf;
     QuadTwiddles tw;
-    load_quad_twiddles(tw, T, lane);
+    load_quad_twiddles(tw, Tg, lane);
+    // the eight wave-uniform level-1 twiddles live in scalar registers for the whole kernel (loaded once, here): loaded inside the
+    // loop they have to be proven unclobbered on every path, and the s_setprio of the forward phase below is one more thing that
+    // defeats that proof -- they would come back as vector loads with a wait each (tests/test_codegen.py counts them)
+    cd Tu[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) Tu[k] = Tg[k];
+    const cd *T = Tu;
     const QuadLane q = quad_lane(lane);
     __syncthreads();
     // the four waves of polynomial p maintain its table together: wave (g, h) owns coefficients 64 qa + lane + 256 k
@@ -579,7 +586,12 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
         const int inext = i + 1 < nsteps ? i + 1 : i;          // the last step re-requests its own slices (never used)
         cd keep[4], send[4];
         if (g == 0) {
+            // group 0 is the step's critical path (two forward transforms against one): it issues ahead of the group-1 wave it shares
+            // its SIMD with, which has ~2,500 cycles of slack before barrier 1.  -3 to -4 % at 128 and 256 bootstraps, +-0 at one
+            // (profiles/r04_b_oct_floor.txt; with the twiddles in SGPRs -- as a builtin in round 3's kernel it cost 5 %).
+            __builtin_amdgcn_s_setprio(3);
             oct_forward<L, BGBIT, 0, L0>(A, Tp, at, sr, lane, K, sc, T, tw, q, keep, send, tr);
+            __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 sc[k * 64 + lane] = keep[k];
