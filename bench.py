@@ -348,6 +348,23 @@ def extra_configs(pkg, key, ck, dev, ceil=None):
     except Exception as e:
         out["config5_mixed_stream_131072"] = {"error": f"{type(e).__name__}: {e}", "verified": False}
 
+    # ---- the small-launch floor: what every scalar gates.* call of the reference costs here, and every circuit level of at most one
+    # bootstrap per CU (nine of the adder's 17): k_blind_rotate_oct + key switch at 1 and 256 gates
+    try:
+        rec = {}
+        for Bs in (1, 256):
+            xs = torch.from_numpy(key.enc(np.ones(Bs, np.int64), 6000 + Bs).view(np.int32)).to(dev)
+            ys = torch.empty_like(xs)
+            dt, kt = timed(lambda: ck.ctx.gate_batch_dev("NAND", xs, xs, None, ys), 10, ck.ctx)
+            ok = bool(np.array_equal(key.dec(ys.cpu().numpy().view(np.uint32)), np.zeros(Bs, bool)))      # NAND(1, 1) = 0
+            rec[f"x{Bs}"] = {"ms_per_call": dt * 1e3, "blind_rotate_ms": kt.br_ms / 10, "keyswitch_ms": kt.ks_ms / 10, "decrypts_ok": ok}
+        out["small_launch_floor"] = {
+            "workload": "one NAND gate, and 256, through tfhe_gate_batch_dev (the eight-wave kernel: 700 sequential CMUX steps whatever the width "
+                        "up to one bootstrap per CU) -- the latency of a scalar gates.* call and of a narrow circuit level",
+            **rec, "verified": all(v["decrypts_ok"] for v in rec.values()), "dominant_kernel": "k_blind_rotate_oct<3,6>"}
+    except Exception as e:
+        out["small_launch_floor"] = {"error": f"{type(e).__name__}: {e}", "verified": False}
+
     # ---- config 4: programmable bootstrap, Uint5 (N = 2048, n = 1071), LUT evaluation, batch 512
     ck5 = None
     try:
