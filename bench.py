@@ -478,6 +478,9 @@ def init_distributed(rank, world, dev, want):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+        # one node: gloo would otherwise pick its interface by resolving the container's hostname, which may not resolve
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     if want != "nccl":
         return dist, None, "gloo"
