@@ -712,6 +712,14 @@ def main():
                                   "attributed to clocks here rather than guessed",
                           "rank0": sampler.summary()},
         }
+        try:                                             # the nominal peak assumes 2.4 GHz; the blind rotate runs power-limited below it
+            mhz = line["telemetry"]["rank0"]["sclk_mhz_mean"]
+            pk = FP64_VECTOR_PEAK_TFLOPS * mhz / 2400.0
+            line["roofline"]["peak_at_measured_clock"] = pk
+            line["roofline"]["frac_at_measured_clock"] = tflops / pk
+            line["roofline"]["measured_clock_mhz"] = mhz
+        except Exception:
+            pass
         if per_rank:
             line["per_rank"] = per_rank
         if key_broadcast_ms is not None:
