@@ -26,6 +26,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "../../include/tfhe_hip.h"
@@ -143,6 +144,41 @@ class CloudKey {
 
   private:
     tfhe_ctx *ctx_ = nullptr;
+};
+
+// One cloud key on SEVERAL GPUs of a node, used from ONE process (a Go service: one goroutine per device instead of one
+// process per GPU; the reference's own concurrency is one evaluator per goroutine, trgsw.go:227-252).  The key is replicated
+// through the engine's blobs -- exported once from `src`, imported (header-checked) into an empty context per device -- and batch
+// calls shard contiguously, one thread per replica (gates::BatchOnSet below).  devices may repeat an index: two contexts on one
+// GPU are two independent submitters (that is how tests/cpp exercises this on a one-GPU box).
+class CloudKeySet {
+  public:
+    CloudKeySet(const CloudKey &src, const std::vector<int> &devices) : P(src.P)
+    {
+        if (devices.empty()) throw Panic(TFHE_E_INVALID, "CloudKeySet needs at least one device");
+        const std::vector<uint8_t> bsk = src.Export(0), ksk = src.Export(1);
+        for (int d : devices) {
+            auto ck = CloudKey::Empty(P, d);
+            ck->Import(0, bsk);
+            ck->Import(1, ksk);
+            replicas_.push_back(std::move(ck));
+        }
+    }
+    // every visible GPU once
+    static std::vector<int> AllDevices()
+    {
+        int n = 0;
+        check(tfhe_device_count(&n));
+        std::vector<int> d(n);
+        for (int i = 0; i < n; i++) d[i] = i;
+        return d;
+    }
+    size_t size() const { return replicas_.size(); }
+    const CloudKey &operator[](size_t i) const { return *replicas_[i]; }
+    params::Params P;
+
+  private:
+    std::vector<std::unique_ptr<CloudKey>> replicas_;
 };
 } // namespace cloudkey
 
@@ -369,6 +405,31 @@ inline std::vector<Ciphertext> batch(int op, const std::vector<std::array<Cipher
     for (auto &p : in) { a.push_back(p[0]); b.push_back(p[1]); }
     return run(op, a, b, nullptr, ck);
 }
+// the same over the replicas of a CloudKeySet: contiguous shards [g B/G, (g+1) B/G), one thread per replica
+inline std::vector<Ciphertext> run_on_set(int op, const std::vector<Ciphertext> &a, const std::vector<Ciphertext> &b,
+                                          const std::vector<Ciphertext> *c, const cloudkey::CloudKeySet &set)
+{
+    const size_t n1 = (size_t)set.P.n + 1, B = a.size(), G = set.size();
+    if (a.size() != b.size() || (c && c->size() != a.size())) throw Panic(TFHE_E_INVALID, "operand counts differ");
+    std::vector<uint32_t> fa = detail::flatten(a, n1), fb = detail::flatten(b, n1), fc, out(fa.size());
+    if (c) fc = detail::flatten(*c, n1);
+    std::vector<int> rc(G, TFHE_OK);
+    std::vector<std::string> err(G);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < G; g++) {
+        const size_t lo = B * g / G, hi = B * (g + 1) / G;
+        if (hi == lo) continue;
+        th.emplace_back([&, g, lo, hi] {
+            rc[g] = tfhe_gate_batch(set[g].ctx(), nullptr, op, fa.data() + lo * n1, fb.data() + lo * n1, c ? fc.data() + lo * n1 : nullptr,
+                                    out.data() + lo * n1, (int)(hi - lo));
+            if (rc[g]) err[g] = tfhe_last_error();          // the message is thread-local: take it where it was set
+        });
+    }
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+        if (rc[g]) throw Panic(rc[g], err[g]);
+    return detail::unflatten(out, n1);
+}
 } // namespace detail_g
 
 // gates.go:26-104
@@ -405,6 +466,19 @@ inline std::vector<Ciphertext> BatchOR(const Pairs &in, const cloudkey::CloudKey
 inline std::vector<Ciphertext> BatchXOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_XOR, in, ck); }
 inline std::vector<Ciphertext> BatchNOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_NOR, in, ck); }
 inline std::vector<Ciphertext> BatchXNOR(const Pairs &in, const cloudkey::CloudKey &ck) { return detail_g::batch(TFHE_OP_XNOR, in, ck); }
+// gates.Batch* over several GPUs from one process: op = TFHE_OP_NAND ... TFHE_OP_ORYN (MUX through BatchMUXOnSet)
+inline std::vector<Ciphertext> BatchOnSet(int op, const Pairs &in, const cloudkey::CloudKeySet &set)
+{
+    std::vector<Ciphertext> a, b;
+    for (auto &p : in) { a.push_back(p[0]); b.push_back(p[1]); }
+    return detail_g::run_on_set(op, a, b, nullptr, set);
+}
+inline std::vector<Ciphertext> BatchMUXOnSet(const std::vector<std::array<Ciphertext, 3>> &in, const cloudkey::CloudKeySet &set)
+{
+    std::vector<Ciphertext> a, b, c;
+    for (auto &t : in) { a.push_back(t[0]); b.push_back(t[1]); c.push_back(t[2]); }
+    return detail_g::run_on_set(TFHE_OP_MUX, a, b, &c, set);
+}
 } // namespace gates
 
 } // namespace tfhe

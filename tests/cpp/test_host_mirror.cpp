@@ -81,6 +81,31 @@ int main()
         EXPECT(dec(r_nor[i]) == !(A[i] || B[i]), "BatchNOR %d", i);
         EXPECT(dec(r_xnor[i]) == (A[i] == B[i]), "BatchXNOR %d", i);
     }
+    // one cloud key on several devices from ONE process (here: two contexts on the one GPU of the box): the key
+    // travels as header-checked blobs, the batch is sharded contiguously over one thread per replica, and every output word
+    // equals the single-context result
+    {
+        cloudkey::CloudKeySet set(ck, {0, 0});
+        EXPECT(set.size() == 2 && cloudkey::CloudKeySet::AllDevices().size() >= 1, "CloudKeySet");
+        gates::Pairs seven;
+        std::vector<std::array<gates::Ciphertext, 3>> mux7;
+        for (int i = 0; i < 7; i++) {                        // ragged: shards of 3 and 4
+            seven.push_back({enc(i & 1), enc((i >> 1) & 1)});
+            mux7.push_back({enc(i & 1), enc((i >> 1) & 1), enc((i >> 2) & 1)});
+        }
+        auto one = gates::BatchXOR(seven, ck), two = gates::BatchOnSet(TFHE_OP_XOR, seven, set);
+        bool same = one.size() == two.size();
+        for (size_t i = 0; same && i < one.size(); i++) same = one[i].P == two[i].P;
+        EXPECT(same, "BatchOnSet(XOR) differs from the single-context batch");
+        auto m = gates::BatchMUXOnSet(mux7, set);
+        for (int i = 0; i < 7; i++) {
+            EXPECT(dec(m[i]) == ((i & 1) ? ((i >> 1) & 1) : ((i >> 2) & 1)), "BatchMUXOnSet %d", i);
+            EXPECT(m[i].P == gates::MUX(mux7[i][0], mux7[i][1], mux7[i][2], ck).P, "BatchMUXOnSet %d differs from scalar MUX", i);
+        }
+        bool threw = false;                                  // a blob of another parameter set is refused
+        try { auto other = cloudkey::CloudKey::Empty(params::Security128Bit()); other->Import(0, ck.Export(0)); } catch (const Panic &) { threw = true; }
+        EXPECT(threw, "importing an 80-bit key blob into a 128-bit context must panic");
+    }
     // Prepare + Bootstrap seam (BASELINE config 1 goes through this)
     evaluator::Evaluator ev(ck);
     auto ca = enc(1), cb = enc(1);
