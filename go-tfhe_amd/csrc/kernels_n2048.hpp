@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
 #pragma unroll
         for (int k = 0; k < 8; k++) y[k] = y[k] + sc[wpart][k * 64 + lane];
         clk.mark(4);
-        fft512_inverse<kPhasePrio ? 2 : -1, 0>(y, sc[wpart], table, tw, ts, lane);  // table carries conj(c1)/1024
+        // two workgroups per CU (kPhasePrio): the inverse's second exchange runs in registers, not through LDS (negacyclic_fft.hpp,
+        // row8_transpose: -2.2 % at Uint5 x 512, -6.9 % for the extended-table form at Uint6 x 64; at one four-wave workgroup per CU it costs 0.9 %)
+        fft512_inverse<kPhasePrio ? 2 : -1, 0, kPhasePrio>(y, sc[wpart], table, tw, ts, lane);  // table carries conj(c1)/1024
         // undo the radix-2 level, x[a] = y0[a] + y1[a], x[a+8] = conj(rho)(y0[a] - y1[a]), for the wave's OWN points
         // a = 4h + q: it sends the sibling's four values and receives its own four -- half the traffic of exchanging
         // all eight, and both waves do the same work

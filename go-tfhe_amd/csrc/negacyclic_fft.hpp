@@ -118,6 +118,64 @@ __device__ __forceinline__ void wave_lds_order()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Exchange 1 of a 512-point transform WITHOUT LDS: (reg m; lane 8b + c) <-> (reg b; lane 8m + c) transposes the eight registers against
+// lane bits 5, 4, 3 -- v_permlane32_swap for bit 5 (16 instructions for eight complex doubles), v_permlane16_swap for bit 4 (16), and
+// for bit 3, where gfx950 has no swap instruction, v_cndmask_b32_dpp row_ror:8 (32): 64 instructions against eight ds_write_b128 +
+// eight ds_read_b128.  Eight instructions per store / load pair is too dear wherever the VALU is the busier pipe (the two-wave
+// N = 1024 kernel: +0.5 to +4.5 %, profiles/r04_g_radix8_register_exchange.txt; the radix-4 kernels' exchange 1 needs only four per
+// pair, kernels_quad.hpp) -- it pays in ONE place: the inverse transform of k_blind_rotate_2048 at two workgroups per CU, the most
+// LDS-bound spot of the path (-2.2 % at Uint5 x 512, -2.9 % at x 1,024; the forward transform there: -0.4 %, both: +2 %).
+__device__ __forceinline__ void x1_swap32(double &a, double &b)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void x1_swap16(double &a, double &b)
+{
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a), blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ void x1_swap8(cd &a, cd &b)
+{
+    const int aw[4] = {__double2loint(a.re), __double2hiint(a.re), __double2loint(a.im), __double2hiint(a.im)};
+    const int bw[4] = {__double2loint(b.re), __double2hiint(b.re), __double2loint(b.im), __double2hiint(b.im)};
+    int na[4], nb[4];
+    const unsigned long long clear = 0x00FF00FF00FF00FFull, set = 0xFF00FF00FF00FF00ull;
+    asm("s_mov_b64 vcc, %[lo]\n\t"
+        "v_cndmask_b32_dpp %[na0], %[b0], %[a0], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[na1], %[b1], %[a1], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[na2], %[b2], %[a2], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[na3], %[b3], %[a3], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_mov_b64 vcc, %[hi]\n\t"
+        "v_cndmask_b32_dpp %[nb0], %[a0], %[b0], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[nb1], %[a1], %[b1], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[nb2], %[a2], %[b2], vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %[nb3], %[a3], %[b3], vcc row_ror:8 row_mask:0xf bank_mask:0xf"
+        : [na0] "=&v"(na[0]), [na1] "=&v"(na[1]), [na2] "=&v"(na[2]), [na3] "=&v"(na[3]), [nb0] "=&v"(nb[0]), [nb1] "=&v"(nb[1]),
+          [nb2] "=&v"(nb[2]), [nb3] "=&v"(nb[3])
+        : [a0] "v"(aw[0]), [a1] "v"(aw[1]), [a2] "v"(aw[2]), [a3] "v"(aw[3]), [b0] "v"(bw[0]), [b1] "v"(bw[1]), [b2] "v"(bw[2]),
+          [b3] "v"(bw[3]), [lo] "s"(clear), [hi] "s"(set)
+        : "vcc");
+    a = cd{__hiloint2double(na[1], na[0]), __hiloint2double(na[3], na[2])};
+    b = cd{__hiloint2double(nb[1], nb[0]), __hiloint2double(nb[3], nb[2])};
+}
+__device__ __forceinline__ void row8_transpose(cd (&x)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) { x1_swap32(x[i].re, x[i + 4].re); x1_swap32(x[i].im, x[i + 4].im); }
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((i & 2) == 0) { x1_swap16(x[i].re, x[i + 2].re); x1_swap16(x[i].im, x[i + 2].im); }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) x1_swap8(x[i], x[i + 1]);
+}
+
 // Per-wave exchange scratch: 8 rows of 72 sixteen-byte slots (64 used + 8 pad).  With this
 // stride both exchange patterns are conflict-free for ds_write_b128 (8 contiguous lanes ->
 // 8 contiguous slots) and ds_read_b128 (the four 16-lane service groups each touch 16
@@ -321,7 +379,8 @@ __device__ __forceinline__ void fft512_forward(cd (&x)[8], cd *sc, const cd *__r
     if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_OUT);
     twist_all_dft8(x, tw.l3, ts.l3);
 }
-template <int PRIO_IN = -1, int PRIO_OUT = 0>
+// X1_REG: the second exchange (exchange 1 backwards) in registers (row8_transpose above)
+template <int PRIO_IN = -1, int PRIO_OUT = 0, bool X1_REG = false>
 __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__restrict__ table,
                                                const LaneTwiddles &tw, const TwStep &ts, int lane)
 {
@@ -339,13 +398,18 @@ __device__ __forceinline__ void fft512_inverse(cd (&x)[8], cd *sc, const cd *__r
     FFT_MIX1(64);
     dft8<-1>(x);
     twist_all_conj(x, tw.l2, ts.l2);
+    if constexpr (X1_REG) {
+        row8_transpose(x);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
 #pragma unroll
-    for (int b = 0; b < 8; b++) sc[SL1R(b)] = x[b];
-    wave_lds_order();
+        for (int b = 0; b < 8; b++) sc[SL1R(b)] = x[b];
+        wave_lds_order();
 #pragma unroll
-    for (int m = 0; m < 8; m++) x[m] = sc[SL1W(m)];
-    wave_lds_order();
-    FFT_MIX1(64);
+        for (int m = 0; m < 8; m++) x[m] = sc[SL1W(m)];
+        wave_lds_order();
+        FFT_MIX1(64);
+    }
     if constexpr (PRIO_IN >= 0) TFHE_PRIO(PRIO_OUT);
     dft8<-1>(x);
 #pragma unroll
