@@ -264,6 +264,16 @@ __global__ __launch_bounds__(256 * EXT) void k_blind_rotate_2048(BlindRotateArgs
     LaneTwiddles tw;
     const cd *table = A.tw + (size_t)h * kTwCount1024;
     load_lane_twiddles(tw, table, lane);
+    // Two workgroups per CU: the loop carries s_setprio builtins, which de-scalarise in-loop wave-uniform loads -- the 15 level-1
+    // twiddles of a step came back as vector loads with a wait each.  They live in scalar registers for the whole kernel instead
+    // (loaded once, here; 60 SGPRs): Uint5 x 512 5.125 -> 5.056 ms.  (Not the extended-table form: there the same hoist spills,
+    // 5.5 -> 8.3 ms; and the one-workgroup-per-CU form has no s_setprio and scalar loads anyway.)
+    cd Tu[16];
+    if constexpr (!KEYS_FIRST && EXT == 1) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Tu[k] = table[k];
+        table = Tu;
+    }
     __syncthreads();
     uint32_t *T = accL[comp][p];
     // Wave h owns the digit points a in [4h, 4h+4) and a + 8 of its polynomial, i.e. coefficients

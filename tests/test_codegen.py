@@ -39,7 +39,9 @@ EXPECT = {
     # 16 key-slice loads and twice the scalar loads.  The instances with phase priorities (s_setprio builtins in the loop, two
     # waves per SIMD) carry their 2 x 15 level-1 twiddle loads as vector loads: measured faster than keeping them scalar
     # with register-tied priorities (kernels_n2048.hpp) -- the counts are pinned so that a further change shows up
-    "k_blind_rotate_2048<22, false, 1>": (10, 68, 256, 0),
+    # (round 4: the two-workgroups-per-CU instance keeps its 16 level-1 twiddles in SGPRs, loaded once ahead of the loops: its vector
+    # loads are the 2 x 16 key slices + set-up again)
+    "k_blind_rotate_2048<22, false, 1>": (5, 40, 256, 0),
     "k_blind_rotate_2048<22, true, 1>": (20, 38, 256, 0),
     "k_blind_rotate_2048<22, false, 2>": (5, 68, 256, 0),
     "k_blind_rotate_512<18>": (15, 25, 256, 0),
