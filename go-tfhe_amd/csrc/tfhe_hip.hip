@@ -1250,7 +1250,7 @@ int tfhe_keygen_cloud_seeded(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1
 // rejected (TFHE_E_INVALID) instead of being installed as garbage.
 namespace {
 constexpr uint64_t kKeyBlobMagic = 0x0159454B45484654ull;       // "TFHEKEY\x01", little-endian
-constexpr uint32_t kKeyLayoutVersion = 3;                        // bump whenever a device key layout changes
+constexpr uint32_t kKeyLayoutVersion = 4;                        // bump whenever a device key layout changes (4: key-switching key rows padded to 128-byte lines)
 struct KeyBlobHeader {
     uint64_t magic;
     uint32_t layout, which;
