@@ -564,10 +564,10 @@ __global__ __launch_bounds__(512, 1) void k_blind_rotate_oct(BlindRotateArgs A)
     const int nsteps = A.nsteps;
     PhaseClock tr;
     tr.start();
-    // The key slices of a step are requested in the IDLE part of the previous step -- group 1 right after its products (it
-    // then waits ~2,900 cycles for group 0 at barrier 1), group 0 right after barrier 1 (it waits for group 1's inverse) -- so
-    // the 8 or 16 loads per wave, their address arithmetic and their queueing at the CU's one address path are off the
-    // critical path, and a step starts with its decomposition.  K is one register set for both groups (a wave is in one).
+    // The key slices of a step are requested during the previous step, where nothing waits for them -- group 1 right after its
+    // products (ahead of barrier 1), group 0 right after barrier 1 (it then waits for group 1's inverse) -- so the 8 or 16 loads per
+    // wave, their address arithmetic and their queueing at the CU's one address path are off the critical path, and a step starts
+    // with its decomposition.  K is one register set for both groups (a wave is in one).
     QuadKeys K[L0];
     const int LBg = g == 0 ? 0 : L0;
     auto request_keys = [&](int step) {
