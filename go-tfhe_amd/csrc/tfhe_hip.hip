@@ -6,8 +6,13 @@
 #include "../../include/tfhe_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <linux/futex.h>
 #include <sys/random.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
+#include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstddef>
 #include <cstdarg>
@@ -129,16 +134,19 @@ struct tfhe_ctx {
     // launch is in flight queue here, and the next leader issues ALL of them as one gate batch.
     struct GateReq {
         const uint8_t *ops; int op_uniform; const uint32_t *a, *b, *cc; uint32_t *out; int B;
-        int rc = TFHE_OK; std::string err; bool done = false, lead = false;
-        std::condition_variable cv;     // one per waiting caller: a finished launch wakes the callers it carried and the next leader, nobody else
+        int rc = TFHE_OK; std::string err;
+        std::atomic<int> state{0};      // 0 waiting, 1 done (rc / err are final), 2 promoted to leader
     };
     std::mutex comb_mu;
+    std::atomic<uint32_t> comb_gen{0};  // bumped behind every launch; waiters sleep on it (futex): ONE wake-all per launch
     std::deque<GateReq *> comb_pending;
     bool comb_leader = false;   // some thread is executing (or about to execute) combined launches
     int combine_max = 0;        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
     void *comb_host = nullptr;  // page-locked staging of one combined launch: [a | b | c | out][rows][n+1] + op codes
     size_t comb_host_cap = 0;
     long long comb_launches = 0, comb_requests = 0;     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
+    size_t comb_last_batch = 0;                         // requests the most recent launch carried (the gathering wait's target)
+    std::chrono::steady_clock::time_point comb_last_done{};   // ... and when it finished
     void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
                                                         // reads them after the call has returned
     bool need_sync_all = false;                         // a stream's event could not be recorded: tfhe_ctx_sync falls back to hipDeviceSynchronize
@@ -858,31 +866,52 @@ int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
 // threads issuing scalar gates one launch each would get N x 2.4 ms.  Instead: a caller that finds no launch in flight
 // becomes the LEADER and issues its request at once (a lone caller's latency is unchanged: its request is launched as it
 // always was); callers that arrive meanwhile queue; when the leader's launch is done it hands leadership to the oldest
-// waiter, which issues EVERYTHING queued as one gate batch and distributes the rows.  No timer, no extra thread.
+// waiter, which issues EVERYTHING queued as one gate batch and distributes the rows.  No extra thread; the only waiting is a
+// bounded gathering wait (<= ~200 us) of a leader that takes over right behind a combined launch, so that the callers that launch
+// carried -- who are waking up at that moment -- travel together again instead of one by one or in two alternating cohorts.
+// Waiters sleep on ONE generation word (futex) that every finished launch bumps and wakes: one system call for all of them,
+// no mutex on the wake path.  256 threads x 40 dependent scalar gates: 25 s serialised -> 0.124 s (profiles/r04_d_combine.txt).
 int combine_gate_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
 {
     std::unique_lock<std::mutex> lk(c->comb_mu);
     c->comb_pending.push_back(&me);
+    bool gather;
     if (c->comb_leader) {
-        me.cv.wait(lk, [&] { return me.done || me.lead; });
-        if (me.done) {
+        // wait without the queue mutex: sleep on the generation word, which every finished launch bumps and wakes (one system
+        // call for all waiters); a waiter whose own request is not settled yet goes back to sleep on the new value
+        lk.unlock();
+        int st;
+        for (;;) {
+            const uint32_t gen = c->comb_gen.load(std::memory_order_acquire);
+            if ((st = me.state.load(std::memory_order_acquire)) != 0) break;
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c->comb_gen), FUTEX_WAIT_PRIVATE, gen, nullptr, nullptr, 0);
+        }
+        if (st == 1) {
             if (me.rc) g_err = me.err;
             return me.rc;
         }
-        // Promoted under contention.  The callers the previous launch carried are waking up this very moment and will be back
-        // with their next request within microseconds; launching without them makes two cohorts that take turns (each launch
-        // half as full as it could be at the same cost).  Let them queue: re-check the queue a few times, at most ~200 us --
-        // 8 % of the launch this wait precedes -- and stop as soon as it no longer grows.  A lone caller never gets here.
+        lk.lock();
+        gather = true;                                  // promoted under contention
+    } else {
+        c->comb_leader = true;
+        // a fresh leader right behind a combined launch is not a lone caller: it is the first of that launch's callers to be back
+        // (the queue was empty when the launch ended because the launch had carried everybody)
+        gather = c->comb_last_batch > 1 && std::chrono::steady_clock::now() - c->comb_last_done < std::chrono::microseconds(500);
+    }
+    if (gather) {
+        // The callers the previous launch carried are waking up this very moment and will be back with their next request within
+        // microseconds; launching without them makes two cohorts that take turns (each launch half as full as it could be at the same
+        // cost), or -- when the launch carried everybody -- a launch for the first one back alone.  Let them queue: re-check the queue
+        // a few times, at most ~200 us (8 % of the launch this wait precedes); stop as soon as it no longer grows, or as many callers
+        // are queued as the previous launch carried (in steady state: everybody is back).  A lone caller never gets here.
         size_t seen = c->comb_pending.size();
-        for (int round = 0, still = 0; round < 10 && still < 2; round++) {
+        for (int round = 0, still = 0; round < 10 && still < 2 && seen < c->comb_last_batch; round++) {
             lk.unlock();
             std::this_thread::sleep_for(std::chrono::microseconds(20));
             lk.lock();
             still = c->comb_pending.size() == seen ? still + 1 : 0;
             seen = c->comb_pending.size();
         }
-    } else {
-        c->comb_leader = true;
     }
     // leader: `me` is the oldest pending request; take it and as many of the following as one launch may carry
     std::vector<tfhe_ctx::GateReq *> batch;
@@ -893,23 +922,25 @@ int combine_gate_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
         total += c->comb_pending.front()->B;
         c->comb_pending.pop_front();
     }
+    c->comb_last_batch = batch.size();
     lk.unlock();
     int rc;
     if (batch.size() == 1) rc = gate_batch_serial(c, me.ops, me.op_uniform, me.a, me.b, me.cc, me.out, me.B);
     else rc = run_combined(c, batch);
     const std::string err = rc ? g_err : std::string();
     lk.lock();
+    c->comb_last_done = std::chrono::steady_clock::now();
     for (auto *r : batch) {
+        if (r == &me) continue;
         r->rc = rc;
         if (rc) r->err = err;
-        r->done = true;
-        if (r != &me) r->cv.notify_one();               // under the lock: a woken caller's request object dies when it returns
+        r->state.store(1, std::memory_order_release);   // the request object may die from here on: nothing touches it afterwards
     }
     if (c->comb_pending.empty()) c->comb_leader = false;
-    else {                                              // leadership passes to the oldest waiter
-        c->comb_pending.front()->lead = true;
-        c->comb_pending.front()->cv.notify_one();
-    }
+    else c->comb_pending.front()->state.store(2, std::memory_order_release);      // leadership passes to the oldest waiter
+    lk.unlock();
+    c->comb_gen.fetch_add(1, std::memory_order_release);
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c->comb_gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     return rc;
 }
 

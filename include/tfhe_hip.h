@@ -232,10 +232,11 @@ int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, 
  * tfhe_ctx_sync).
  *
  * Concurrent callers of the host-pointer variant (any number of threads on ONE context) are COMBINED, not serialised: a
- * launch of 1 ... 256 bootstraps costs the same ~2.4 ms, so while one caller's launch is in flight the others queue, and the
+ * launch of 1 ... 256 bootstraps costs the same ~2.3 ms, so while one caller's launch is in flight the others queue, and the
  * next launch carries ALL queued requests as one gate batch with per-item op codes; each caller gets exactly its rows back --
- * bit-identical to what a call on its own returns (a gate's result depends on its own operands only).  There is no timer
- * and no extra thread: a lone caller is launched at once, exactly as before.  Calls of more than TFHE_OPT_COMBINE_MAX gates
+ * bit-identical to what a call on its own returns (a gate's result depends on its own operands only).  There is no extra
+ * thread and a lone caller is launched at once, exactly as before; only a caller that takes the lead right behind a combined
+ * launch waits (bounded, <= ~0.2 ms) for the callers that launch carried to come back.  Calls of more than TFHE_OPT_COMBINE_MAX gates
  * take the context for themselves.  (The reference's scalar gates.* share one evaluator that is not goroutine-safe,
  * gates.go:19-23; its concurrency is one pooled evaluator per goroutine, trgsw.go:227-252 -- this is what replaces it.)
  * If a combined launch fails, every call it carried returns that error. */
