@@ -817,7 +817,6 @@ int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
     const size_t need = planes * plane + total;
     if (need > c->comb_host_cap) {
         if (c->comb_host) (void)hipHostFree(c->comb_host);
-    for (void *h : c->hdr_host) if (h) (void)hipHostFree(h);
         c->comb_host = nullptr; c->comb_host_cap = 0;
         const size_t cap = need < ((size_t)1 << 22) ? ((size_t)1 << 22) : need + need / 2;
         hipError_t e = hipHostMalloc(&c->comb_host, cap, hipHostMallocDefault);
@@ -1047,6 +1046,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->comb_host) (void)hipHostFree(c->comb_host);
+    for (void *h : c->hdr_host) if (h) (void)hipHostFree(h);
     for (auto &pr : c->pipe_ev)
         for (auto &e : pr) if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {c->h2d_stream, c->d2h_stream}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }

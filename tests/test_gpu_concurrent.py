@@ -146,3 +146,37 @@ def test_combined_launch_error_reaches_every_caller_and_the_context_survives(key
         t.join()
     assert len(errs) == 8 and all("bad op code" in e for e in errs)
     assert len(oks) == 8 and all(np.array_equal(o, oks[0]) for o in oks)
+
+
+def test_key_export_survives_the_first_combined_launch_of_a_context(keys_small, pkg):
+    # regression: the page-locked header of tfhe_key_export_dev and the combiner's page-locked staging are separate allocations
+    # with separate lifetimes (the first combined launch of a context allocates its staging; it must not touch the header)
+    from conftest import gpu_params
+    k = keys_small
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    try:
+        ctx = ck.ctx
+        before = [ctx.key_export_dev(w).cpu() for w in (0, 1)]
+        rs = np.random.RandomState(8)
+        a = rs.randint(0, 2**32, size=(1, k.p.n + 1), dtype=np.uint64).astype(np.uint32)
+        gate = threading.Barrier(8)
+        outs = [None] * 8
+
+        def run(i):
+            gate.wait()
+            outs[i] = ctx.gate_batch("NAND", a, a)
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(8)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert ctx.get_option("combine_launches") >= 1
+        assert all(np.array_equal(o, outs[0]) for o in outs)
+        for w in (0, 1):
+            again = ctx.key_export_dev(w).cpu()
+            assert torch.equal(again, before[w])
+            ctx.key_import_dev(w, again.cuda())
+        assert np.array_equal(ctx.gate_batch("NAND", a, a), outs[0])
+    finally:
+        ck.close()
