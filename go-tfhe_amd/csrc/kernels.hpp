@@ -536,8 +536,11 @@ __device__ __forceinline__ int ks_items(const KeySwitchArgs &A, int B)
     return c < B ? c : B;
 }
 
+// `parts` > 1 (few ciphertexts, many idle CUs): workgroup (item, part) sums the rows of digit range `part` of the item and adds its
+// partial sum to the output k_ks_init prepared (32-bit atomics: subtraction mod 2^32 is associative and commutative, so the result is
+// the same word for word) -- one ciphertext of the Uint5 set is 6,144 rows = 26 MB through ONE CU otherwise (0.34 ms; 16 parts: 0.04).
 template <int CH, typename IdxT>
-__global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
+__global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A, int parts)
 {
     constexpr int U = 8;                      // key rows in flight per wave
     __shared__ IdxT rows[9216 + 4 * U];
@@ -545,12 +548,14 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
     __shared__ int count;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int N = A.N, t = A.t, bb = A.basebit, base1 = (1 << bb) - 1;
-    if (A.count && (int)blockIdx.x >= *A.count) return;
-    const uint32_t *ta = A.trlwe + (size_t)blockIdx.x * 2 * N;
+    const int item = parts > 1 ? (int)blockIdx.x / parts : (int)blockIdx.x, part = parts > 1 ? (int)blockIdx.x - item * parts : 0;
+    if (A.count && item >= *A.count) return;
+    const uint32_t *ta = A.trlwe + (size_t)item * 2 * N;
     if (tid == 0) count = 0;
     __syncthreads();
     const uint32_t prec = 1u << (32 - (1 + bb * t));
-    for (int idx = tid; idx < N * t; idx += 256) {
+    const int idx_lo = (int)((long long)part * N * t / parts), idx_hi = (int)((long long)(part + 1) * N * t / parts);
+    for (int idx = idx_lo + tid; idx < idx_hi; idx += 256) {
         const int i = idx / t, j = idx - i * t;
         // SampleExtractIndexAssign(.,0,.): P[0] = A[0], P[i] = ~A[N-i]  (trlwe_ops.go:13-19)
         const uint32_t ai = i == 0 ? ta[0] : ~ta[N - i];
@@ -591,10 +596,11 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A)
         r[0] = acc[c].x; r[1] = acc[c].y; r[2] = acc[c].z; r[3] = acc[c].w;
     }
     __syncthreads();
-    uint32_t *out = A.out + (size_t)blockIdx.x * (A.n + 1);
+    uint32_t *out = A.out + (size_t)item * (A.n + 1);
     for (int x = tid; x <= A.n; x += 256) {
         const uint32_t sum = red[0][x] + red[1][x] + red[2][x] + red[3][x];
-        out[x] = (x == A.n ? ta[N] : 0u) - sum;      // out = (0,...,0,b) - sum rows (keyswitch.go:18-33)
+        if (parts > 1) { if (sum) atomicAdd(out + x, 0u - sum); }
+        else out[x] = (x == A.n ? ta[N] : 0u) - sum;      // out = (0,...,0,b) - sum rows (keyswitch.go:18-33)
     }
 }
 

@@ -515,9 +515,19 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
     }
     // row indices fit 16 bits for the 2-bit key-switch base of the N=1024 sets (halves the LDS list)
     const bool small_idx = ksk_rows_packed(c->P) < 65535;
+    // few ciphertexts: the digit list of each is dealt to `parts` workgroups (up to 16, at least 256 digits each), so that a
+    // lone ciphertext's rows do not all go through one CU
+    int parts = c->num_cus / B;
+    if (parts > 16) parts = 16;
+    while (parts > 1 && c->P.N * c->P.t / parts < 256) parts--;
+    if (parts < 1) parts = 1;
+    if (parts > 1) {
+        const size_t tot = (size_t)B * (c->P.n + 1);
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
+    }
 #define KS_LAUNCH(CH)                                                                                   \
-    if (small_idx) hipLaunchKernelGGL((k_extract_keyswitch<CH, uint16_t>), dim3(B), dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((k_extract_keyswitch<CH, uint32_t>), dim3(B), dim3(256), 0, st, a)
+    if (small_idx) hipLaunchKernelGGL((k_extract_keyswitch<CH, uint16_t>), dim3(B * parts), dim3(256), 0, st, a, parts); \
+    else hipLaunchKernelGGL((k_extract_keyswitch<CH, uint32_t>), dim3(B * parts), dim3(256), 0, st, a, parts)
     switch (ch) {
     case 1: KS_LAUNCH(1); break;
     case 2: KS_LAUNCH(2); break;
