@@ -340,7 +340,9 @@ int make_quad_key(tfhe_ctx *c, hipStream_t st)
 }
 
 // Byte-column copy of the packed key-switching key for k_keyswitch_mfma (base-4 sets; keyswitch_mfma.hpp).
-constexpr int kKsMfmaMinDefault = 1;        // it wins from one ciphertext on (0.09 vs 0.27 ms; 0.135 vs 0.51 ms at 1,024)
+constexpr int kKsMfmaMinDefault = 24;       // from 24 ciphertexts on; below, the per-ciphertext gather dealt to up to 16 workgroups per
+                                            // ciphertext is quicker (128-bit set: 0.026-0.030 vs 0.038-0.040 ms at 1...16, 0.042 vs 0.038 at 31;
+                                            // at 1,024: 0.135 vs 0.51 ms for the tiled vector kernel) -- profiles/r04_t_small_launches_uint.txt
 constexpr int kKsMfmaChunk = 1024;           // ciphertexts per one-hot matrix (38 MB at the 128-bit set)
 int ks_mfma_pieces(const tfhe_params &P) { return P.t * P.N / (16 >> P.basebit); }      // 16-K pieces: K = N t base
 bool ks_mfma_shape(const tfhe_params &P)

@@ -112,7 +112,8 @@ enum {
                                   kernels; default = number of CUs; 0 = always the two-wave kernel                       */
     TFHE_OPT_OCT_MAX = 2,      /* ... and of those, up to this many the eight-wave kernel; default = number of CUs       */
     TFHE_OPT_KS_MFMA_MIN = 3,  /* batches of at least this many ciphertexts use the matrix-core key switch where the key
-                                  shape has one (default 1); 0 = never (the vector-ALU kernels)                          */
+                                  shape has one (default 24: below, the per-ciphertext gather is quicker); 0 = never
+                                  (the vector-ALU kernels).  Every key-switch kernel is bit-exact: same words either way  */
     TFHE_OPT_FROZEN = 4,       /* 1 while a captured hipGraph may hold the intermediate buffers' addresses (set by the
                                   library, see tfhe_ctx_reserve); the caller clears it once those graphs are destroyed    */
     TFHE_OPT_COMBINE_MAX = 5,  /* tfhe_gate_batch calls of at most this many gates are COMBINED with concurrent callers'

@@ -121,7 +121,8 @@ def test_matrix_core_keyswitch_equals_vector_kernels(pkg, oracle, request, which
     ckv = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
     ckv.ctx.set_option("ks_mfma_min", 0)
     ckm = pkg.CloudKey(gpu_params(pkg, k.p), ksk=k.ksk)
-    assert ckm.ctx.get_option("ks_mfma_min") == 1 and ckv.ctx.get_option("ks_mfma_min") == 0
+    assert ckm.ctx.get_option("ks_mfma_min") == 24 and ckv.ctx.get_option("ks_mfma_min") == 0      # default: matrix cores from 24 ciphertexts on
+    ckm.ctx.set_option("ks_mfma_min", 1)                                                            # here: always
     rs = np.random.RandomState(23)
     for B in ((1, 5, 33, 256, 257, 1025, 2100) if which in ("small", "uint2") else (1, 33, 300)):
         trl = rand_u32(rs, (B, 2, k.p.N))
@@ -528,12 +529,12 @@ def test_options_are_per_context_and_validated(pkg, keys_small):
         del os.environ["TFHE_QUAD_MAX"], os.environ["TFHE_KS_MFMA_MIN"]
     ctx = ck.ctx
     cus = ctx.get_option("quad_max")
-    assert cus > 0 and ctx.get_option("oct_max") == cus and ctx.get_option("ks_mfma_min") == 1 and ctx.get_option("frozen") == 0
+    assert cus > 0 and ctx.get_option("oct_max") == cus and ctx.get_option("ks_mfma_min") == 24 and ctx.get_option("frozen") == 0
     ctx.set_option("quad_max", 7); ctx.set_option("oct_max", 3); ctx.set_option("ks_mfma_min", 100)
     assert (ctx.get_option("quad_max"), ctx.get_option("oct_max"), ctx.get_option("ks_mfma_min")) == (7, 3, 100)
     for name in ("quad_max", "oct_max", "ks_mfma_min"):
         ctx.set_option(name, -1)
-    assert (ctx.get_option("quad_max"), ctx.get_option("oct_max"), ctx.get_option("ks_mfma_min")) == (cus, cus, 1)
+    assert (ctx.get_option("quad_max"), ctx.get_option("oct_max"), ctx.get_option("ks_mfma_min")) == (cus, cus, 24)
     with pytest.raises(pkg.TfheError, match="unknown option"):
         ctx._check(ctx._lib.tfhe_ctx_set_option(ctx._h, 99, 1))
     # the same gates under every dispatch setting: identical ciphertexts
