@@ -180,3 +180,52 @@ def test_key_export_survives_the_first_combined_launch_of_a_context(keys_small, 
         assert np.array_equal(ctx.gate_batch("NAND", a, a), outs[0])
     finally:
         ck.close()
+
+
+def test_combiner_stress_random_sizes_ops_and_oversize_calls(keys_small, ck_small, pkg):
+    # 24 threads x 12 calls each with random batch sizes (1 ... 40, and some beyond TFHE_OPT_COMBINE_MAX, which take the context for
+    # themselves), random per-item op codes incl. MUX, no start barrier: leaders, waiters, promotions, gathering waits and oversize
+    # calls interleave freely.  Every result must equal the same call issued alone with combining switched off.
+    k, ctx = keys_small, ck_small.ctx
+    n1 = k.p.n + 1
+    T, CALLS = 24, 12
+    rs = np.random.RandomState(99)
+    pool = rs.randint(0, 2**32, size=(3, 400, n1), dtype=np.uint64).astype(np.uint32)
+    plan = []
+    for t in range(T):
+        calls = []
+        for _ in range(CALLS):
+            B = int(rs.choice([1, 1, 1, 2, 7, 40, 130]))
+            off = int(rs.randint(0, 400 - B))
+            ops = rs.randint(0, 11, size=B).astype(np.uint8)
+            calls.append((B, off, ops))
+        plan.append(calls)
+    ctx.set_option("combine_max", 0)
+    want = [[ctx.gate_batch(ops, pool[0, off:off + B], pool[1, off:off + B], pool[2, off:off + B]) for B, off, ops in calls]
+            for calls in plan]
+    ctx.set_option("combine_max", 64)                   # the 130-gate calls are oversize: they bypass the combiner
+    before = ctx.get_option("combine_requests")
+    got = [[None] * CALLS for _ in range(T)]
+    errors = []
+
+    def run(t):
+        try:
+            for i, (B, off, ops) in enumerate(plan[t]):
+                got[t][i] = ctx.gate_batch(ops, pool[0, off:off + B], pool[1, off:off + B], pool[2, off:off + B])
+        except Exception as e:                          # noqa: BLE001 -- reported below, with the thread
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join(timeout=120)
+    try:
+        assert not any(th.is_alive() for th in ts), "a caller never returned (lost wake-up or leadership not handed over)"
+        assert not errors, errors
+        for t in range(T):
+            for i in range(CALLS):
+                assert np.array_equal(got[t][i], want[t][i]), (t, i, plan[t][i][0])
+        assert ctx.get_option("combine_requests") > before
+    finally:
+        ctx.set_option("combine_max", -1)
