@@ -130,23 +130,29 @@ struct tfhe_ctx {
     // staging (grow-only)
     DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_plan, s_t0, s_t1, s_t2, s_t3;
     std::recursive_mutex mu;    // host-pointer calls hold it for their whole duration, _dev calls while they reserve and enqueue
-    // Flat combining of concurrent tfhe_gate_batch callers (combine_gate_request below): requests that arrive while a
-    // launch is in flight queue here, and the next leader issues ALL of them as one gate batch.
+    // Flat combining of concurrent host-pointer callers (combine_request below): requests that arrive while a launch is in flight
+    // queue here, and the next leader issues ALL of them as one batch.  One queue per kind of request -- gate batches
+    // (tfhe_gate_batch) and programmable bootstraps (tfhe_bootstrap_batch) -- because a launch carries one kind.
     struct GateReq {
+        int kind;                       // 0: gates (ops / op_uniform, a, b, cc), 1: bootstraps through a table (a = in, b = tv, op_uniform = tv_per_item)
         const uint8_t *ops; int op_uniform; const uint32_t *a, *b, *cc; uint32_t *out; int B;
         int rc = TFHE_OK; std::string err;
         std::atomic<int> state{0};      // 0 waiting, 1 done (rc / err are final), 2 promoted to leader
     };
-    std::mutex comb_mu;
-    std::atomic<uint32_t> comb_gen{0};  // bumped behind every launch; waiters sleep on it (futex): ONE wake-all per launch
-    std::deque<GateReq *> comb_pending;
-    bool comb_leader = false;   // some thread is executing (or about to execute) combined launches
+    struct CombQueue {
+        std::mutex mu;
+        std::atomic<uint32_t> gen{0};   // bumped behind every launch; waiters sleep on it (futex): ONE wake-all per launch
+        std::deque<GateReq *> pending;
+        bool leader = false;            // some thread is executing (or about to execute) combined launches
+        size_t last_batch = 0;          // requests the most recent launch carried (the gathering wait's target)
+        std::chrono::steady_clock::time_point last_done{};   // ... and when it finished
+    };
+    CombQueue comb[2];
     int combine_max = 0;        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
     void *comb_host = nullptr;  // page-locked staging of one combined launch: [a | b | c | out][rows][n+1] + op codes
     size_t comb_host_cap = 0;
     long long comb_launches = 0, comb_requests = 0;     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
-    size_t comb_last_batch = 0;                         // requests the most recent launch carried (the gathering wait's target)
-    std::chrono::steady_clock::time_point comb_last_done{};   // ... and when it finished
+    std::vector<uint32_t> gate_tv_host;                 // the gate test vector (a combined bootstrap launch carries one table per item)
     void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
                                                         // reads them after the call has returned
     bool need_sync_all = false;                         // a stream's event could not be recorded: tfhe_ctx_sync falls back to hipDeviceSynchronize
@@ -812,6 +818,8 @@ int gate_batch_serial(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uin
     return TFHE_OK;
 }
 
+int comb_staging(tfhe_ctx *c, size_t need);       // page-locked staging of the combined launches (below)
+
 // One launch for the requests of several callers: their rows are packed behind one another in page-locked staging
 // (one host copy per operand and request, ONE transfer per operand plane), every item carries its own op code, and
 // each caller gets its rows back.  A gate's result depends on its own operands only -- not on its position in a batch,
@@ -827,14 +835,7 @@ int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
     for (auto *r : batch) { total += (size_t)r->B; any_c = any_c || r->cc; }
     const size_t plane = total * n1 * 4, planes = any_c ? 4 : 3;          // a, b, [c], out
     const size_t need = planes * plane + total;
-    if (need > c->comb_host_cap) {
-        if (c->comb_host) (void)hipHostFree(c->comb_host);
-        c->comb_host = nullptr; c->comb_host_cap = 0;
-        const size_t cap = need < ((size_t)1 << 22) ? ((size_t)1 << 22) : need + need / 2;
-        hipError_t e = hipHostMalloc(&c->comb_host, cap, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-        c->comb_host_cap = cap;
-    }
+    if ((rc = comb_staging(c, need))) return rc;
     char *ha = static_cast<char *>(c->comb_host), *hb = ha + plane, *hc = any_c ? hb + plane : nullptr;
     char *ho = ha + (planes - 1) * plane;
     uint8_t *hops = reinterpret_cast<uint8_t *>(ha + planes * plane);
@@ -872,6 +873,83 @@ int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
     return TFHE_OK;
 }
 
+// The host-pointer programmable bootstrap of ONE caller (evaluator.BootstrapLUT, programmable_bootstrap.go:93-115).
+int bootstrap_batch_serial(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out, int B)
+{
+    int rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
+    const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
+    if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_out.reserve(inb)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
+    if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
+                               c->s_out.as<uint32_t>(), B, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int comb_staging(tfhe_ctx *c, size_t need)
+{
+    if (need <= c->comb_host_cap) return TFHE_OK;
+    if (c->comb_host) (void)hipHostFree(c->comb_host);
+    c->comb_host = nullptr; c->comb_host_cap = 0;
+    const size_t cap = need < ((size_t)1 << 22) ? ((size_t)1 << 22) : need + need / 2;
+    hipError_t e = hipHostMalloc(&c->comb_host, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+    c->comb_host_cap = cap;
+    return TFHE_OK;
+}
+
+// One launch for the programmable bootstraps of several callers: rows packed as in run_combined, ONE TABLE PER ITEM (each
+// caller's table -- its own per-item tables, or its one table repeated, or the gate test vector where it passed none).  An
+// item's result depends on its own sample and table only, and the launch stays within the kernel shape a call on its own
+// would have run (combine_cap), so every caller receives exactly the words the serial path would have given it.
+int run_combined_pbs(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
+{
+    int rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t n1 = (size_t)c->P.n + 1, tw = (size_t)2 * c->P.N;
+    size_t total = 0;
+    for (auto *r : batch) total += (size_t)r->B;
+    const size_t rows = total * n1 * 4, tabs = total * tw * 4;
+    if ((rc = comb_staging(c, 2 * rows + tabs))) return rc;
+    char *hin = static_cast<char *>(c->comb_host), *hout = hin + rows, *htv = hout + rows;
+    size_t at = 0;
+    for (auto *r : batch) {
+        memcpy(hin + at * n1 * 4, r->a, (size_t)r->B * n1 * 4);
+        const uint32_t *tv = r->b ? r->b : c->gate_tv_host.data();
+        if (r->b && r->op_uniform) memcpy(htv + at * tw * 4, tv, (size_t)r->B * tw * 4);
+        else for (int k = 0; k < r->B; k++) memcpy(htv + (at + (size_t)k) * tw * 4, tv, tw * 4);
+        at += (size_t)r->B;
+    }
+    if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_out.reserve(rows)) || (rc = c->s_tv.reserve(tabs))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_in0.p, hin, rows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->s_tv.p, htv, tabs, hipMemcpyHostToDevice, c->stream));
+    if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), c->s_tv.as<uint32_t>(), 1, c->s_out.as<uint32_t>(), (int)total, c->stream)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(hout, c->s_out.p, rows, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    at = 0;
+    for (auto *r : batch) {
+        memcpy(r->out, hout + at * n1 * 4, (size_t)r->B * n1 * 4);
+        at += (size_t)r->B;
+    }
+    c->comb_launches++;
+    c->comb_requests += (long long)batch.size();
+    return TFHE_OK;
+}
+
+// Items one combined launch may carry.  Gates, and bootstraps at the N = 1024, L = 3 shape, are exact integers whatever kernel
+// runs them: a launch may be as long as the pipelined host path allows.  At the other shapes (tolerance
+// regime) the kernels of different launch shapes round differently, so a combined launch of table bootstraps stays within the
+// shape of the calls it carries: at most one bootstrap per CU (requests longer than that are not combined at all).
+int combine_cap(const tfhe_ctx *c, int kind)
+{
+    return kind == 0 || c->shape == kShapeN1024_L3_B6 ? pipe_items(c) : c->num_cus;
+}
+
 // Flat combining (the reference's concurrency is goroutine fan-out over pooled evaluators, trgsw.go:227-252; its scalar
 // gates.* serialise on one evaluator, gates.go:19-23,136-142).  A launch of 1 ... 256 bootstraps costs the same 2.4 ms, so N
 // threads issuing scalar gates one launch each would get N x 2.4 ms.  Instead: a caller that finds no launch in flight
@@ -882,20 +960,21 @@ int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
 // carried -- who are waking up at that moment -- travel together again instead of one by one or in two alternating cohorts.
 // Waiters sleep on ONE generation word (futex) that every finished launch bumps and wakes: one system call for all of them,
 // no mutex on the wake path.  256 threads x 40 dependent scalar gates: 25 s serialised -> 0.124 s (profiles/r04_d_combine.txt).
-int combine_gate_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
+int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
 {
-    std::unique_lock<std::mutex> lk(c->comb_mu);
-    c->comb_pending.push_back(&me);
+    tfhe_ctx::CombQueue &Q = c->comb[me.kind];
+    std::unique_lock<std::mutex> lk(Q.mu);
+    Q.pending.push_back(&me);
     bool gather;
-    if (c->comb_leader) {
+    if (Q.leader) {
         // wait without the queue mutex: sleep on the generation word, which every finished launch bumps and wakes (one system
         // call for all waiters); a waiter whose own request is not settled yet goes back to sleep on the new value
         lk.unlock();
         int st;
         for (;;) {
-            const uint32_t gen = c->comb_gen.load(std::memory_order_acquire);
+            const uint32_t gen = Q.gen.load(std::memory_order_acquire);
             if ((st = me.state.load(std::memory_order_acquire)) != 0) break;
-            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c->comb_gen), FUTEX_WAIT_PRIVATE, gen, nullptr, nullptr, 0);
+            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&Q.gen), FUTEX_WAIT_PRIVATE, gen, nullptr, nullptr, 0);
         }
         if (st == 1) {
             if (me.rc) g_err = me.err;
@@ -904,10 +983,10 @@ int combine_gate_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
         lk.lock();
         gather = true;                                  // promoted under contention
     } else {
-        c->comb_leader = true;
+        Q.leader = true;
         // a fresh leader right behind a combined launch is not a lone caller: it is the first of that launch's callers to be back
         // (the queue was empty when the launch ended because the launch had carried everybody)
-        gather = c->comb_last_batch > 1 && std::chrono::steady_clock::now() - c->comb_last_done < std::chrono::microseconds(500);
+        gather = Q.last_batch > 1 && std::chrono::steady_clock::now() - Q.last_done < std::chrono::microseconds(500);
     }
     if (gather) {
         // The callers the previous launch carried are waking up this very moment and will be back with their next request within
@@ -915,43 +994,48 @@ int combine_gate_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
         // cost), or -- when the launch carried everybody -- a launch for the first one back alone.  Let them queue: re-check the queue
         // a few times, at most ~200 us (8 % of the launch this wait precedes); stop as soon as it no longer grows, or as many callers
         // are queued as the previous launch carried (in steady state: everybody is back).  A lone caller never gets here.
-        size_t seen = c->comb_pending.size();
-        for (int round = 0, still = 0; round < 10 && still < 2 && seen < c->comb_last_batch; round++) {
+        size_t seen = Q.pending.size();
+        for (int round = 0, still = 0; round < 10 && still < 2 && seen < Q.last_batch; round++) {
             lk.unlock();
             std::this_thread::sleep_for(std::chrono::microseconds(20));
             lk.lock();
-            still = c->comb_pending.size() == seen ? still + 1 : 0;
-            seen = c->comb_pending.size();
+            still = Q.pending.size() == seen ? still + 1 : 0;
+            seen = Q.pending.size();
         }
     }
     // leader: `me` is the oldest pending request; take it and as many of the following as one launch may carry
     std::vector<tfhe_ctx::GateReq *> batch;
-    const int cap = pipe_items(c);
+    const int cap = combine_cap(c, me.kind);
     int total = 0;
-    while (!c->comb_pending.empty() && (batch.empty() || total + c->comb_pending.front()->B <= cap)) {
-        batch.push_back(c->comb_pending.front());
-        total += c->comb_pending.front()->B;
-        c->comb_pending.pop_front();
+    while (!Q.pending.empty() && (batch.empty() || total + Q.pending.front()->B <= cap)) {
+        batch.push_back(Q.pending.front());
+        total += Q.pending.front()->B;
+        Q.pending.pop_front();
     }
-    c->comb_last_batch = batch.size();
+    Q.last_batch = batch.size();
     lk.unlock();
     int rc;
-    if (batch.size() == 1) rc = gate_batch_serial(c, me.ops, me.op_uniform, me.a, me.b, me.cc, me.out, me.B);
-    else rc = run_combined(c, batch);
+    if (me.kind == 0) {
+        if (batch.size() == 1) rc = gate_batch_serial(c, me.ops, me.op_uniform, me.a, me.b, me.cc, me.out, me.B);
+        else rc = run_combined(c, batch);
+    } else {
+        if (batch.size() == 1) rc = bootstrap_batch_serial(c, me.a, me.b, me.op_uniform, me.out, me.B);
+        else rc = run_combined_pbs(c, batch);
+    }
     const std::string err = rc ? g_err : std::string();
     lk.lock();
-    c->comb_last_done = std::chrono::steady_clock::now();
+    Q.last_done = std::chrono::steady_clock::now();
     for (auto *r : batch) {
         if (r == &me) continue;
         r->rc = rc;
         if (rc) r->err = err;
         r->state.store(1, std::memory_order_release);   // the request object may die from here on: nothing touches it afterwards
     }
-    if (c->comb_pending.empty()) c->comb_leader = false;
-    else c->comb_pending.front()->state.store(2, std::memory_order_release);      // leadership passes to the oldest waiter
+    if (Q.pending.empty()) Q.leader = false;
+    else Q.pending.front()->state.store(2, std::memory_order_release);      // leadership passes to the oldest waiter
     lk.unlock();
-    c->comb_gen.fetch_add(1, std::memory_order_release);
-    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&c->comb_gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    Q.gen.fetch_add(1, std::memory_order_release);
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&Q.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
     return rc;
 }
 
@@ -1036,6 +1120,7 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     for (int j = 0; j < P->N; j++) tv[P->N + j] = 0x20000000u;
     if ((rc = c->gate_tv.reserve(tv.size() * sizeof(uint32_t)))) return rc;
     HIP_TRY(hipMemcpy(c->gate_tv.p, tv.data(), tv.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->gate_tv_host = std::move(tv);
     guard.c = nullptr;
     *out = c;
     return TFHE_OK;
@@ -1557,17 +1642,12 @@ int tfhe_bootstrap_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, in
     if (rc) return rc;
     if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (B == 0) return TFHE_OK;
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
-    const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
-    if ((rc = c->s_in0.reserve(inb)) || (rc = c->s_out.reserve(inb)) || (tvb && (rc = c->s_tv.reserve(tvb)))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->s_in0.p, in, inb, hipMemcpyHostToDevice, c->stream));
-    if (tv) HIP_TRY(hipMemcpyAsync(c->s_tv.p, tv, tvb, hipMemcpyHostToDevice, c->stream));
-    if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), tv ? c->s_tv.as<uint32_t>() : nullptr, tv_per_item,
-                               c->s_out.as<uint32_t>(), B, c->stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, inb, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return TFHE_OK;
+    if (!c->have_bsk) return fail(TFHE_E_NOKEY, "bootstrapping key not loaded");
+    if (!c->have_ksk) return fail(TFHE_E_NOKEY, "key-switching key not loaded");
+    // concurrent callers are combined like those of tfhe_gate_batch (combine_request): one launch of 1 ... 256 bootstraps costs the same
+    if (B > c->combine_max || B > combine_cap(c, 1)) return bootstrap_batch_serial(c, in, tv, tv_per_item, out, B);
+    tfhe_ctx::GateReq me{1, nullptr, tv_per_item ? 1 : 0, in, tv, nullptr, out, B};
+    return combine_request(c, me);
 }
 
 int tfhe_bootstrap_extended_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *lut, int lut_per_item, int ext,
@@ -1609,8 +1689,8 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
         if (op_uniform == TFHE_OP_MUX && !cc) return fail(TFHE_E_INVALID, "MUX needs the third operand");
     }
     if (B > c->combine_max) return gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
-    tfhe_ctx::GateReq me{ops, op_uniform, a, b, cc, out, B};
-    return combine_gate_request(c, me);
+    tfhe_ctx::GateReq me{0, ops, op_uniform, a, b, cc, out, B};
+    return combine_request(c, me);
 }
 
 int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, uint32_t *out, int B)

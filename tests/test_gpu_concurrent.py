@@ -229,3 +229,65 @@ def test_combiner_stress_random_sizes_ops_and_oversize_calls(keys_small, ck_smal
         assert ctx.get_option("combine_requests") > before
     finally:
         ctx.set_option("combine_max", -1)
+
+
+@pytest.mark.parametrize("which", ["80", "uint5"])
+def test_concurrent_programmable_bootstraps_are_combined_and_bit_identical(oracle, pkg, request, which):
+    # evaluator.BootstrapLUT from many threads on one context (programmable_bootstrap.go:93-115): callers with their OWN table,
+    # with per-item tables, and with none (the gate test vector) travel in one launch with one table per item; every result is,
+    # word for word, what the same call returns alone with combining switched off.  "80": exact regime (N = 1024, L = 3);
+    # "uint5" (n reduced): tolerance regime -- still bit-identical, because a combined launch stays within the kernel shape
+    # of a lone call (at most one bootstrap per CU).
+    from conftest import KeySet, gpu_params
+    if which == "80":
+        k = request.getfixturevalue("keys80")
+        modulus = 2
+    else:
+        k = KeySet(oracle, "uint5", 0x7F4E0061, n_override=24, torus=False)
+        modulus = 32
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    try:
+        ctx = ck.ctx
+        rs = np.random.RandomState(71)
+        n1, N = k.p.n + 1, k.p.N
+        luts = [oracle.lut_generate(k.p, [(a * x + b) % modulus for x in range(modulus)]) for a, b in ((1, 0), (3, 1), (modulus - 1, 2))]
+        T = 40
+        reqs = []
+        for t in range(T):
+            B = [1, 1, 2, 5][t % 4]
+            msgs = rs.randint(0, modulus, B)
+            cts = np.stack([oracle.encrypt_message(k.p, k.rng, int(m), modulus, k.s0) for m in msgs])
+            if t % 5 == 4:
+                tv = None                                           # the gate test vector
+            elif t % 5 == 3:
+                tv = np.stack([luts[(t + i) % 3] for i in range(B)])   # one table per item
+            else:
+                tv = luts[t % 3]
+            reqs.append((cts, tv, msgs))
+        ctx.set_option("combine_max", 0)
+        want = [ctx.bootstrap_batch(cts, tv) for cts, tv, _ in reqs]
+        ctx.set_option("combine_max", -1)
+        before_l, before_r = ctx.get_option("combine_launches"), ctx.get_option("combine_requests")
+        got = [None] * T
+        gate = threading.Barrier(T)
+
+        def run(t):
+            gate.wait()
+            got[t] = ctx.bootstrap_batch(reqs[t][0], reqs[t][1])
+
+        ts = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join(timeout=120)
+        assert not any(th.is_alive() for th in ts)
+        for t in range(T):
+            assert np.array_equal(got[t], want[t]), f"request {t} differs from the serial path"
+        assert ctx.get_option("combine_launches") > before_l and ctx.get_option("combine_requests") - before_r >= 2
+        # and the values are right: a shared-table request decrypts to f(m)
+        cts, tv, msgs = reqs[1]
+        fa, fb = [(1, 0), (3, 1), (modulus - 1, 2)][1 % 3]
+        dec = [oracle.decrypt_message(k.p, modulus, k.s0, np.ascontiguousarray(o)) for o in got[1]]
+        assert dec == [int((fa * m + fb) % modulus) for m in msgs]
+    finally:
+        ck.close()

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -15,9 +16,57 @@
 
 #define CK(x) do { int rc_ = (x); if (rc_) { std::printf("FAILED %s: %s\n", #x, tfhe_last_error()); std::exit(1); } } while (0)
 
+// `combine_bench.bin T pbs`: T threads each issue a chain of 8 DEPENDENT programmable bootstraps at the Uint5 set (n = 1071, N = 2048),
+// every thread through its own lookup table (evaluator.BootstrapLUT, programmable_bootstrap.go:93-115).
+static int pbs_mode(int T)
+{
+    tfhe_params P{1071, 2048, 11, 1, 22, 6, 3};                // Uint5 (params.go:362-398)
+    tfhe_ctx *ctx = nullptr;
+    CK(tfhe_ctx_create(&P, 0, &ctx));
+    std::mt19937_64 gen(9);
+    std::vector<uint32_t> s0(P.n), s1(P.N);
+    for (auto &v : s0) v = gen() & 1;
+    for (auto &v : s1) v = gen() & 1;
+    CK(tfhe_keygen_cloud(ctx, s0.data(), s1.data(), 1.0e-7, 1.0e-15, 13));
+    const int n1 = P.n + 1;
+    std::vector<std::vector<uint32_t>> in(T, std::vector<uint32_t>(n1)), lut(T, std::vector<uint32_t>((size_t)2 * P.N));
+    for (auto &v : in) for (auto &w : v) w = (uint32_t)gen();
+    for (auto &v : lut) for (auto &w : v) w = (uint32_t)gen();
+    auto chain = [&](int t) {
+        std::vector<uint32_t> a(in[t]), b(n1);
+        for (int i = 0; i < 8; i++) {
+            CK(tfhe_bootstrap_batch(ctx, a.data(), lut[t].data(), 0, b.data(), 1));
+            a.swap(b);
+        }
+    };
+    auto run = [&](int threads) {
+        std::vector<std::thread> th;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < threads; t++) th.emplace_back(chain, t);
+        for (auto &x : th) x.join();
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    chain(0);
+    int l0, r0, l1, r1;
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_LAUNCHES, &l0));
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_REQUESTS, &r0));
+    const double one = run(1), ms = run(T);
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_LAUNCHES, &l1));
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_REQUESTS, &r1));
+    CK(tfhe_ctx_set_option(ctx, TFHE_OPT_COMBINE_MAX, 0));
+    const int Ts = T < 8 ? T : 8;
+    const double serial = run(Ts);
+    std::printf("{\"mode\": \"pbs uint5\", \"threads\": %d, \"pbs_calls\": %d, \"ms\": %.1f, \"combined_launches\": %d, \"calls_carried\": %d, "
+                "\"one_thread_8_pbs_ms\": %.1f, \"serialised_%d_threads_ms\": %.1f, \"serialised_all_threads_projected_ms\": %.0f}\n",
+                T, 8 * T, ms, l1 - l0, r1 - r0, one, Ts, serial, serial / Ts * T);
+    CK(tfhe_ctx_destroy(ctx));
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     const int T = argc > 1 ? std::atoi(argv[1]) : 256;
+    if (argc > 2 && std::string(argv[2]) == "pbs") return pbs_mode(T);
     tfhe_params P{700, 1024, 10, 3, 6, 2, 9};                 // 128-bit set (params.go:151-180)
     tfhe_ctx *ctx = nullptr;
     CK(tfhe_ctx_create(&P, 0, &ctx));
