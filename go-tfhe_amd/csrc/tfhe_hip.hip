@@ -955,11 +955,12 @@ int combine_cap(const tfhe_ctx *c, int kind)
 // threads issuing scalar gates one launch each would get N x 2.4 ms.  Instead: a caller that finds no launch in flight
 // becomes the LEADER and issues its request at once (a lone caller's latency is unchanged: its request is launched as it
 // always was); callers that arrive meanwhile queue; when the leader's launch is done it hands leadership to the oldest
-// waiter, which issues EVERYTHING queued as one gate batch and distributes the rows.  No extra thread; the only waiting is a
+// waiter, which issues EVERYTHING queued (of its kind: gates, or bootstraps through a table) as one batch and distributes the rows.  No extra thread; the only waiting is a
 // bounded gathering wait (<= ~200 us) of a leader that takes over right behind a combined launch, so that the callers that launch
 // carried -- who are waking up at that moment -- travel together again instead of one by one or in two alternating cohorts.
 // Waiters sleep on ONE generation word (futex) that every finished launch bumps and wakes: one system call for all of them,
-// no mutex on the wake path.  256 threads x 40 dependent scalar gates: 25 s serialised -> 0.124 s (profiles/r04_d_combine.txt).
+// no mutex on the wake path.  256 threads x 40 dependent scalar gates: 25 s serialised -> 0.124 s; 256 threads x 8 dependent Uint5
+// bootstraps through their own tables: 8.4 s -> 67 ms (profiles/r04_d_combine.txt).
 int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
 {
     tfhe_ctx::CombQueue &Q = c->comb[me.kind];
