@@ -7,8 +7,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(LIB_DIR, "libtfhe_hip.so")  # env override: kernel experiments
-# (source, extra flags): the fp64 kernels get the max-ILP machine scheduler, the rest the default one
-SOURCES = [("tfhe_hip.hip", []), ("blind_rotate.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
+# (source, extra flags): machine-scheduler options per kernel family, each measured (csrc/blind_rotate.hip has the table)
+MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+SOURCES = [("tfhe_hip.hip", []), ("blind_rotate.hip", MAX_ILP), ("blind_rotate_oct.hip", MAX_ILP + ["-mllvm", "-enable-post-misched=0"]),
+           ("blind_rotate_n2048.hip", [])]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "tfhe_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]

@@ -1,9 +1,12 @@
-// blind_rotate.hip -- instantiates and launches the blind-rotate / external-product kernels.
-// Separate translation unit: built with -mllvm -amdgpu-sched-strategy=max-ilp (see build.py).
+// blind_rotate.hip -- instantiates and launches the blind-rotate / external-product kernels of the N = 1024 and N = 512 shapes
+// (two-wave and four-wave forms) and dispatches the rest.  The fp64 kernels live in translation units of their own because the
+// machine scheduler that suits them differs (build.py; measured per kernel family, profiles/r04_ab_scheduler_matrix.txt):
+//   blind_rotate.hip        -mllvm -amdgpu-sched-strategy=max-ilp                        (-6 % at 1,024 gates against the default)
+//   blind_rotate_oct.hip    the same + -mllvm -enable-post-misched=0                      (eight-wave kernel: -2.2 % at one bootstrap)
+//   blind_rotate_n2048.hip  the default scheduler                                         (N = 2048: -2.5 % at Uint5 x 512)
 #include "launch_blind_rotate.hpp"
 
 
-#include "kernels_n2048.hpp"
 #include "kernels_n512.hpp"
 #include "kernels_quad.hpp"
 
@@ -32,8 +35,7 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
             // (257...512 bootstraps) loses to the paired two-wave form below -- 4.31 vs 4.05 ms at 512, measured again in
             // round 3 with its twiddle loads scalar (profiles/r03_b_midsize.txt) -- and is no longer instantiated.
             if (cnt <= oct_limit && shape != kShapeN1024_L1_B23) {
-                if (shape == kShapeN1024_L3_B6) hipLaunchKernelGGL((k_blind_rotate_oct<3, 6>), g, dim3(512), 0, st, a);
-                else hipLaunchKernelGGL((k_blind_rotate_oct<2, 10>), g, dim3(512), 0, st, a);
+                launch_blind_rotate_oct(shape, a, cnt, st);
             } else {
                 switch (shape) {
                 case kShapeN1024_L3_B6: hipLaunchKernelGGL((k_blind_rotate_quad<3, 6, 1, 1>), g, dim3(256), 0, st, a); break;
@@ -82,21 +84,9 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_blind_rotate<2, 10>), g, dim3(128), 0, st, a); break;
         case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_blind_rotate<1, 23>), g, dim3(128), 0, st, a); break;
         case kShapeN512_L1_B18: hipLaunchKernelGGL((k_blind_rotate_512<18>), g, dim3(64), 0, st, a); break;
-        default:
-            // one bootstrap per four-wave workgroup whatever the launch size (two bootstraps per eight-wave workgroup
-            // were 2 % faster while a step had five barriers; with four, free-running workgroups win by 7 %)
-            if (cnt <= num_cus) hipLaunchKernelGGL((k_blind_rotate_2048<22, true>), g, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_blind_rotate_2048<22, false>), g, dim3(256), 0, st, a);
-            break;
+        default: launch_blind_rotate_2048(a, cnt, num_cus, st); break;
         }
     }
-}
-
-void launch_blind_rotate_ext2(const BlindRotateArgs &a0, int B, hipStream_t st)
-{
-    BlindRotateArgs a = a0;
-    a.batch = B;
-    hipLaunchKernelGGL((k_blind_rotate_2048<22, false, 2>), dim3(B), dim3(512), 0, st, a);
 }
 
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
@@ -107,7 +97,7 @@ void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_ind
     case kShapeN1024_L2_B10: hipLaunchKernelGGL((k_external_product<2, 10>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
     case kShapeN1024_L1_B23: hipLaunchKernelGGL((k_external_product<1, 23>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
     case kShapeN512_L1_B18: hipLaunchKernelGGL((k_external_product_512<18>), dim3(B), dim3(64), 0, st, bsk, tw, key_index, in, out, offset); break;
-    default: hipLaunchKernelGGL((k_external_product_2048<22>), dim3(B), dim3(128), 0, st, bsk, tw, key_index, in, out, offset); break;
+    default: launch_external_product_2048(bsk, tw, key_index, in, out, offset, B, st); break;
     }
 }
 

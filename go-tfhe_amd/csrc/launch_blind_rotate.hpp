@@ -1,7 +1,7 @@
-// launch_blind_rotate.hpp -- the fp64-heavy kernels live in their own translation unit
-// (blind_rotate.hip) so they can be compiled with the max-ILP machine scheduler
-// (-mllvm -amdgpu-sched-strategy=max-ilp: -5 % blind-rotate time, but +35 % on the memory-bound
-// key-switch kernels, which therefore stay in the default-scheduled unit).
+// launch_blind_rotate.hpp -- the fp64-heavy kernels live in their own translation units
+// (blind_rotate*.hip) so they can be compiled with the machine-scheduler options that suit them
+// (max-ILP: -6 % blind-rotate time at N = 1024, but +35 % on the memory-bound key-switch kernels,
+// which therefore stay in the default-scheduled unit, and +2.5 % on the N = 2048 kernels).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -21,6 +21,12 @@ inline bool shape_is_512(int shape) { return shape == kShapeN512_L1_B18; }
 // quad_limit: N = 1024 launches of up to this many items use the four-wave kernel (kernels_quad.hpp);
 // oct_limit: of those, launches of up to this many (and at most one per CU) use the eight-wave kernel.
 void launch_blind_rotate(int shape, const BlindRotateArgs &args, int B, int num_cus, int quad_limit, int oct_limit, hipStream_t st);
+// The pieces of launch_blind_rotate / launch_external_product that live in translation units of their own (blind_rotate_oct.hip,
+// blind_rotate_n2048.hip: other machine-scheduler options, see blind_rotate.hip): one launch of `cnt` items, args already offset.
+void launch_blind_rotate_oct(int shape, const BlindRotateArgs &args, int cnt, hipStream_t st);
+void launch_blind_rotate_2048(const BlindRotateArgs &args, int cnt, int num_cus, hipStream_t st);
+void launch_external_product_2048(const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out, uint32_t offset, int B,
+                                  hipStream_t st);
 // Persistent blind rotate through an extended lookup table with polyExtendFactor 2 (kernels_n2048.hpp, EXT = 2): one
 // eight-wave workgroup per item; args.tv = lut [2][2][N] (tv_stride 0 or 4N), args.in1 / ops / idx unused.
 void launch_blind_rotate_ext2(const BlindRotateArgs &args, int B, hipStream_t st);

@@ -76,11 +76,23 @@ def step_loop_mix(body):
 def asm(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    out = tmp_path_factory.mktemp("asm") / "blind_rotate.s"
-    src = os.path.join(ROOT, "go-tfhe_amd", "csrc", "blind_rotate.hip")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                    "-S", "--cuda-device-only", src, "-o", str(out)], check=True, capture_output=True)
-    text = open(out).read()
+    # the blind-rotate translation units, each with the machine-scheduler options the build gives it (go-tfhe_amd/build.py)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tfhe_build", os.path.join(ROOT, "go-tfhe_amd", "build.py"))
+    bld = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bld)
+    units = [(src, extra) for src, extra in bld.SOURCES if src.startswith("blind_rotate")]
+    assert len(units) == 3, units
+    tmp = tmp_path_factory.mktemp("asm")
+    procs = []
+    for src, extra in units:
+        out = tmp / (src + ".s")
+        procs.append((out, subprocess.Popen([HIPCC] + bld.FLAGS + extra + ["-S", "--cuda-device-only", os.path.join(bld.CSRC, src), "-o", str(out)],
+                                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
+    text = ""
+    for out, pr in procs:
+        assert pr.wait() == 0, out
+        text += open(out).read() + "\n"
     dem = subprocess.run(["c++filt"], input="\n".join(sorted(set(re.findall(r"^(_ZN4tfhe\w+):", text, re.M)))),
                          capture_output=True, text=True, check=True).stdout.splitlines()
     names = dict(zip(sorted(set(re.findall(r"^(_ZN4tfhe\w+):", text, re.M))), dem))
