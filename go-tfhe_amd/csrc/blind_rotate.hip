@@ -3,10 +3,11 @@
 // machine scheduler that suits them differs (build.py; measured per kernel family, profiles/r04_ab_scheduler_matrix.txt):
 //   blind_rotate.hip        -mllvm -amdgpu-sched-strategy=max-ilp                        (-6 % at 1,024 gates against the default)
 //   blind_rotate_oct.hip    the same + -mllvm -enable-post-misched=0                      (eight-wave kernel: -2.2 % at one bootstrap)
-//   blind_rotate_n2048.hip  the default scheduler                                         (N = 2048: -2.5 % at Uint5 x 512)
+//   blind_rotate_n2048.hip  the default scheduler                                         (N = 2048, four-wave instances: -2.5 % at Uint5 x 512)
 #include "launch_blind_rotate.hpp"
 
 
+#include "kernels_n2048.hpp"      // for the extended-table instance only (launch_blind_rotate_ext2)
 #include "kernels_n512.hpp"
 #include "kernels_quad.hpp"
 
@@ -87,6 +88,15 @@ void launch_blind_rotate(int shape, const BlindRotateArgs &a0, int B, int num_cu
         default: launch_blind_rotate_2048(a, cnt, num_cus, st); break;
         }
     }
+}
+
+// The extended-table form of the N = 2048 kernel (EXT = 2: eight waves, one workgroup per CU) is scheduled like the N = 1024 kernels, not like
+// its four-wave siblings: Uint6 x 64 5.52 ms here against 5.87 ms in the default-scheduled unit (tools/ext_bench.py, three rounds on one box).
+void launch_blind_rotate_ext2(const BlindRotateArgs &a0, int B, hipStream_t st)
+{
+    BlindRotateArgs a = a0;
+    a.batch = B;
+    hipLaunchKernelGGL((k_blind_rotate_2048<22, false, 2>), dim3(B), dim3(512), 0, st, a);
 }
 
 void launch_external_product(int shape, const cd *bsk, const cd *tw, int key_index, const uint32_t *in, uint32_t *out,
