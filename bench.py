@@ -465,6 +465,9 @@ def emit(line):
         data = data[os.write(fd, data):]
 
 
+_ABANDONED_THREADS = []       # helper threads stuck inside RCCL (init_distributed): the process then leaves through os._exit
+
+
 def init_distributed(rank, world, dev, want):
     """Process groups of a multi-rank run.  Returns (dist, data_group, backend).
 
@@ -484,16 +487,33 @@ def init_distributed(rank, world, dev, want):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     if want != "nccl":
         return dist, None, "gloo"
-    ok, err, group = 1, None, None
-    try:
-        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300), device_id=dev)
-        probe = torch.ones(1, device=dev)
-        dist.all_reduce(probe, group=group)
-        torch.cuda.synchronize()
-        if int(probe.item()) != world:
-            raise RuntimeError(f"RCCL all-reduce probe returned {probe.item()} on {world} ranks")
-    except Exception as e:                                   # noqa: BLE001
-        ok, err = 0, f"{type(e).__name__}: {e}"
+    # The RCCL group is created and probed on a helper thread with a deadline of our own (TFHE_BENCH_RCCL_TIMEOUT seconds, default
+    # 240): an RCCL that HANGS during initialisation -- rather than failing -- must not take the whole run with it.  A rank whose
+    # probe is still stuck at the deadline votes "unusable" like one whose probe raised; the stuck thread is abandoned (daemon) and
+    # the process leaves through os._exit once the result line is out (finish()).  The group's own timeout is set far beyond the
+    # run so that torch's watchdog does not abort a process that has already moved on to gloo.
+    import threading
+    state = {"ok": 0, "err": "RCCL initialisation still running at the deadline", "group": None}
+
+    def try_rccl():
+        try:
+            torch.cuda.set_device(dev)
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(hours=12), device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe, group=g)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"RCCL all-reduce probe returned {probe.item()} on {world} ranks")
+            state.update(ok=1, err=None, group=g)
+        except Exception as e:                               # noqa: BLE001
+            state.update(ok=0, err=f"{type(e).__name__}: {e}")
+
+    th = threading.Thread(target=try_rccl, daemon=True)
+    th.start()
+    th.join(timeout=float(os.environ.get("TFHE_BENCH_RCCL_TIMEOUT", "240")))
+    if th.is_alive():
+        _ABANDONED_THREADS.append(th)
+    ok, err, group = (0, state["err"], None) if th.is_alive() else (state["ok"], state["err"], state["group"])
     agreed = torch.tensor([ok], dtype=torch.int32)
     dist.all_reduce(agreed, op=dist.ReduceOp.MIN)            # over gloo: the handshake itself cannot depend on RCCL
     if int(agreed.item()) == 1:
@@ -594,10 +614,8 @@ def main():
         else:
             rec = sharded_adder(pkg, p, key, ck, env, args.steps, max(1, args.warmup))
         ck.close()
-        dist.destroy_process_group()
-        if rank == 0:
-            emit({"metric": "gate bootstraps/sec, batch held by rank 0 (scatter + compute + gather timed)", "mode": "sharded",
-                  "value": rec["rate"], "higher_is_better": True, "scaling": "strong", **rec})
+        finish(dist, rank, {"metric": "gate bootstraps/sec, batch held by rank 0 (scatter + compute + gather timed)", "mode": "sharded",
+                            "value": rec["rate"], "higher_is_better": True, "scaling": "strong", **rec})
         return
 
     from go_tfhe_amd import telemetry
@@ -779,11 +797,21 @@ def main():
         if rank == 0:
             line["configs"] = cfg
     ck.close()
+    finish(dist, rank, line)
+
+
+def finish(dist, rank, line):
+    """Leave the process groups and print rank 0's line.  With a helper thread still stuck inside RCCL (init_distributed) the groups
+    are not torn down -- that could wait for the stuck communicator -- and the process leaves through os._exit once the line is out."""
     if dist:
         dist.barrier()
-        dist.destroy_process_group()
+        if not _ABANDONED_THREADS:
+            dist.destroy_process_group()
     if rank == 0:
         emit(line)
+    if _ABANDONED_THREADS:
+        sys.stderr.flush()
+        os._exit(0)
 
 
 class DistEnv:
