@@ -34,7 +34,11 @@ import os
 import sys
 import time
 
-import numpy as np
+# multi-process GPU work on this pool needs dmabuf IPC (the host driver has no legacy IPC: RCCL would fail with
+# hipIpcGetMemHandle: invalid argument); exported on the boxes already -- kept here for any environment built by hand
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
