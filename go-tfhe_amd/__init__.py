@@ -10,5 +10,5 @@ from .params import (Params, Security80Bit, Security110Bit, Security128Bit, Secu
                      SecurityUint3, SecurityUint4, SecurityUint5, SecurityUint6, SecurityUint7, SecurityUint8)
 from ._binding import (Context, PinnedArray, TfheError, OPS, library_path, load_library, exported_symbols,  # noqa: F401
                        declared_symbols)
-from .cloudkey import CloudKey  # noqa: F401
+from .cloudkey import CloudKey, CloudKeySet  # noqa: F401
 from . import gates, evaluator, lut  # noqa: F401

@@ -59,6 +59,7 @@ def load_library():
         "tfhe_device_count": [C.POINTER(C.c_int)],
         "tfhe_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(vp)],
         "tfhe_ctx_destroy": [vp],
+        "tfhe_ctx_clone_to": [vp, C.c_int, C.POINTER(vp)],
         "tfhe_ctx_params": [vp, C.POINTER(Params)],
         "tfhe_ctx_sync": [vp],
         "tfhe_load_bsk_fourier": [vp, f64p],
@@ -180,6 +181,18 @@ class Context:
     def _check(self, rc):
         if rc != 0:
             raise TfheError(rc, self._lib.tfhe_last_error().decode())
+
+    def clone_to(self, device):
+        """tfhe_ctx_clone_to: a replica of this context (parameters, dispatch limits, keys) on GPU `device`, the keys copied
+        GPU to GPU (hipMemcpyPeerAsync; D2D on the same device; host-staged only when the devices are not peers).
+        get_option("clone_path") on the result says which path ran."""
+        other = Context.__new__(Context)
+        other._lib = self._lib
+        other._h = C.c_void_p()
+        other.params = self.params
+        self._check(self._lib.tfhe_ctx_clone_to(self._h, int(device), C.byref(other._h)))
+        other.device = int(device)
+        return other
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -416,7 +429,8 @@ class Context:
                                                   blob.numel() * blob.element_size(), self._stream(stream)))
 
     OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4, "combine_max": 5, "combine_launches": 6,
-               "combine_requests": 7, "ks_wide_ct": 8}
+               "combine_requests": 7, "ks_wide_ct": 8, "clone_path": 9}
+    CLONE_PATHS = {0: "not a clone", 1: "same device (D2D)", 2: "peer copy (xGMI)", 3: "host-staged (no peer access)"}
 
     def set_option(self, name, value):
         """tfhe_ctx_set_option: kernel-dispatch limits for measurements and tests ("quad_max", "oct_max", "ks_mfma_min";

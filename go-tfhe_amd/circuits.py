@@ -207,21 +207,42 @@ class CircuitExecutor:
         torch = self.torch
         C = int(max_instances or wires.shape[1])
         widest = max(sum(3 if g[0] == "MUX" else 1 for g in lvl) for lvl in self.levels)      # a MUX item is three bootstraps
-        self.ctx.reserve(widest * C, with_mux=any(g[0] == "MUX" for lvl in self.levels for g in lvl))
+        try:
+            self.ctx.reserve(widest * C, with_mux=any(g[0] == "MUX" for lvl in self.levels for g in lvl))
+        except Exception as e:
+            if self.ctx.get_option("frozen"):
+                # another executor's graph already froze this context at a smaller size: say what to do about it here,
+                # not only in the library's words
+                raise RuntimeError(
+                    f"the context is frozen by {getattr(self.ctx, '_graphs_alive', 0)} captured graph(s) and its buffers are too small "
+                    f"for this schedule's widest level ({widest} bootstraps x {C} instances): capture the FIRST graph of a shared "
+                    f"context with max_instances large enough for every later one, or release() the earlier executors first "
+                    f"({e})") from e
+            raise
         self.run(wires)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self.run(wires)
+        # graphs alive per CONTEXT, not per executor: several executors may capture on one context, and the context may only
+        # be un-frozen (buffers allowed to move) when the last of them has let go
+        self.ctx._graphs_alive = getattr(self.ctx, "_graphs_alive", 0) + 1
+        self._captured_count = getattr(self, "_captured_count", 0) + 1
         self._captured = True
         return graph
 
     def release(self):
-        """Call once every graph captured through this executor's context has been destroyed: un-freezes the context's
-        intermediate buffers (TFHE_OPT_FROZEN = 0) so that later, larger batches may grow them again."""
+        """Call once every graph captured through THIS executor has been destroyed.  The context counts the captures of all
+        its executors; its intermediate buffers are un-frozen (TFHE_OPT_FROZEN = 0: later, larger batches may grow them
+        again) only when the last executor holding graphs has released -- another executor's replays keep their addresses."""
         self.ctx.sync()
-        self.ctx.set_option("frozen", 0)
+        mine = getattr(self, "_captured_count", 0)
+        alive = max(0, getattr(self.ctx, "_graphs_alive", 0) - mine)
+        self.ctx._graphs_alive = alive
+        self._captured_count = 0
         self._captured = False
+        if alive == 0:
+            self.ctx.set_option("frozen", 0)
 
     def run(self, wires, stream=None):
         """wires: int32 tensor [n_wires][C][n+1] with the input wires filled; updated in place.

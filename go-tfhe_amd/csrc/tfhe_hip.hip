@@ -11,6 +11,7 @@
 #include <sys/syscall.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <climits>
 #include <cmath>
@@ -126,7 +127,8 @@ struct tfhe_ctx {
     int ks_mfma_min = 0;        // batches of at least this many ciphertexts use it
     int ks_wide_ct = 0;         // k_keyswitch_wide: ciphertexts per wave, 0 = by batch size (TFHE_OPT_KS_WIDE_CT)
     DevBuf bskq, twq;           // four-wave layout of the key + its twiddles (N = 1024 shapes, kernels_quad.hpp)
-    bool have_bsk = false, have_ksk = false;
+    // read by tfhe_gate_batch / tfhe_bootstrap_batch before they take any lock (the header promises thread-safe calls): atomics
+    std::atomic<bool> have_bsk{false}, have_ksk{false};
     // staging (grow-only)
     DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_plan, s_t0, s_t1, s_t2, s_t3;
     std::recursive_mutex mu;    // host-pointer calls hold it for their whole duration, _dev calls while they reserve and enqueue
@@ -148,13 +150,14 @@ struct tfhe_ctx {
         std::chrono::steady_clock::time_point last_done{};   // ... and when it finished
     };
     CombQueue comb[2];
-    int combine_max = 0;        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
+    std::atomic<int> combine_max{0};        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
     void *comb_host = nullptr;  // page-locked staging of one combined launch: [a | b | c | out][rows][n+1] + op codes
     size_t comb_host_cap = 0;
-    long long comb_launches = 0, comb_requests = 0;     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
+    std::atomic<long long> comb_launches{0}, comb_requests{0};     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
     std::vector<uint32_t> gate_tv_host;                 // the gate test vector (a combined bootstrap launch carries one table per item)
     void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
                                                         // reads them after the call has returned
+    int clone_path = 0;                                 // TFHE_OPT_CLONE_PATH: how tfhe_ctx_clone_to brought the keys here (0 = not a clone)
     bool need_sync_all = false;                         // a stream's event could not be recorded: tfhe_ctx_sync falls back to hipDeviceSynchronize
 };
 
@@ -941,13 +944,22 @@ int run_combined_pbs(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
     return TFHE_OK;
 }
 
-// Items one combined launch may carry.  Gates, and bootstraps at the N = 1024, L = 3 shape, are exact integers whatever kernel
-// runs them: a launch may be as long as the pipelined host path allows.  At the other shapes (tolerance
-// regime) the kernels of different launch shapes round differently, so a combined launch of table bootstraps stays within the
-// shape of the calls it carries: at most one bootstrap per CU (requests longer than that are not combined at all).
+// Items one combined launch may carry.  At the N = 1024, L = 3, Bgbit = 6 shape (80 / 110 / 128-bit sets) every transform is
+// exact: whatever kernel runs an item, its words are the same, so a launch may be as long as the pipelined
+// host path allows.  At every other shape (tolerance regime) the kernels of different launch shapes round differently -- gates
+// included: the gate test vector goes through the same transforms -- so a combined launch stays within the kernel shape a lone
+// small call runs: at most one bootstrap per CU AND within the four-/eight-wave limits of the context (TFHE_OPT_QUAD_MAX /
+// TFHE_OPT_OCT_MAX overrides move those).  Requests longer than the cap are not combined at all.
 int combine_cap(const tfhe_ctx *c, int kind)
 {
-    return kind == 0 || c->shape == kShapeN1024_L3_B6 ? pipe_items(c) : c->num_cus;
+    (void)kind;
+    if (c->shape == kShapeN1024_L3_B6) return pipe_items(c);
+    int cap = c->num_cus;
+    if (shape_is_1024(c->shape)) {              // the small-launch kernels exist at the N = 1024 shapes only
+        if (c->quad_limit > 0 && c->quad_limit < cap) cap = c->quad_limit;
+        if (c->oct_limit > 0 && c->oct_limit < cap) cap = c->oct_limit;
+    }
+    return cap < 1 ? 1 : cap;
 }
 
 // Flat combining (the reference's concurrency is goroutine fan-out over pooled evaluators, trgsw.go:227-252; its scalar
@@ -993,10 +1005,12 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
         // The callers the previous launch carried are waking up this very moment and will be back with their next request within
         // microseconds; launching without them makes two cohorts that take turns (each launch half as full as it could be at the same
         // cost), or -- when the launch carried everybody -- a launch for the first one back alone.  Let them queue: re-check the queue
-        // a few times, at most ~200 us (8 % of the launch this wait precedes); stop as soon as it no longer grows, or as many callers
+        // until a DEADLINE of 200 us on the steady clock (8 % of the launch this wait precedes; a count of sleeps is not a bound: with
+        // the default 50 us timer slack ten 20 us sleeps take ~0.7 ms); stop as soon as the queue no longer grows, or as many callers
         // are queued as the previous launch carried (in steady state: everybody is back).  A lone caller never gets here.
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
         size_t seen = Q.pending.size();
-        for (int round = 0, still = 0; round < 10 && still < 2 && seen < Q.last_batch; round++) {
+        for (int still = 0; still < 2 && seen < Q.last_batch && std::chrono::steady_clock::now() < deadline;) {
             lk.unlock();
             std::this_thread::sleep_for(std::chrono::microseconds(20));
             lk.lock();
@@ -1004,39 +1018,72 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
             seen = Q.pending.size();
         }
     }
-    // leader: `me` is the oldest pending request; take it and as many of the following as one launch may carry
+    // leader: `me` is the oldest pending request; take it and as many of the following as one launch may carry.  Nothing in the
+    // leader section may throw past this function (the ABI never throws, and every waiter of the batch sleeps until its request is
+    // settled): allocation failures are caught and settle the whole batch with TFHE_E_NOMEM.
     std::vector<tfhe_ctx::GateReq *> batch;
-    const int cap = combine_cap(c, me.kind);
-    int total = 0;
-    while (!Q.pending.empty() && (batch.empty() || total + Q.pending.front()->B <= cap)) {
-        batch.push_back(Q.pending.front());
-        total += Q.pending.front()->B;
-        Q.pending.pop_front();
+    int rc = TFHE_OK;
+    bool individually = false;      // every request of the batch already carries its own result
+    std::string err;
+    try {
+        const int cap = combine_cap(c, me.kind);
+        int total = 0;
+        batch.reserve(Q.pending.size());
+        while (!Q.pending.empty() && (batch.empty() || total + Q.pending.front()->B <= cap)) {
+            batch.push_back(Q.pending.front());
+            total += Q.pending.front()->B;
+            Q.pending.pop_front();
+        }
+        Q.last_batch = batch.size();
+        lk.unlock();
+        auto serial = [&](tfhe_ctx::GateReq &r) {
+            return r.kind == 0 ? gate_batch_serial(c, r.ops, r.op_uniform, r.a, r.b, r.cc, r.out, r.B)
+                               : bootstrap_batch_serial(c, r.a, r.b, r.op_uniform, r.out, r.B);
+        };
+        if (batch.size() == 1) {
+            rc = serial(me);
+            if (rc) err = g_err;
+        } else {
+            rc = me.kind == 0 ? run_combined(c, batch) : run_combined_pbs(c, batch);
+            if (rc) {
+                // A combined launch can fail for a reason that only the COMBINATION has -- the sum of the requests needs buffers a
+                // frozen context (captured hipGraph) may not grow, or page-locked staging that cannot be had -- while each request
+                // on its own would succeed.  The header promises every caller what a lone call returns: re-issue the batch's requests
+                // one by one through the serial path, each with its own result.  (Nothing of a failed launch has reached a caller's
+                // output: rows are handed out only behind a successful launch.)
+                for (auto *r : batch) {
+                    const int rr = serial(*r);
+                    if (r == &me) { rc = rr; if (rr) err = g_err; continue; }
+                    r->rc = rr;
+                    if (rr) r->err = g_err;
+                }
+                individually = true;
+            }
+        }
+        lk.lock();
+    } catch (...) {                                       // std::bad_alloc of the vector / string copies
+        if (!lk.owns_lock()) lk.lock();
+        rc = TFHE_E_NOMEM;
+        try { err = "out of host memory while combining concurrent requests"; } catch (...) {}
     }
-    Q.last_batch = batch.size();
-    lk.unlock();
-    int rc;
-    if (me.kind == 0) {
-        if (batch.size() == 1) rc = gate_batch_serial(c, me.ops, me.op_uniform, me.a, me.b, me.cc, me.out, me.B);
-        else rc = run_combined(c, batch);
-    } else {
-        if (batch.size() == 1) rc = bootstrap_batch_serial(c, me.a, me.b, me.op_uniform, me.out, me.B);
-        else rc = run_combined_pbs(c, batch);
-    }
-    const std::string err = rc ? g_err : std::string();
-    lk.lock();
+    if (!individually)
+        for (auto *r : batch) {
+            if (r == &me) continue;
+            r->rc = rc;
+            if (rc) { try { r->err = err; } catch (...) {} }
+        }
     Q.last_done = std::chrono::steady_clock::now();
-    for (auto *r : batch) {
-        if (r == &me) continue;
-        r->rc = rc;
-        if (rc) r->err = err;
-        r->state.store(1, std::memory_order_release);   // the request object may die from here on: nothing touches it afterwards
+    for (auto *r : batch)
+        if (r != &me) r->state.store(1, std::memory_order_release);   // the request object may die from here on: nothing touches it afterwards
+    if (batch.empty()) {                                  // the catch path before `me` was taken: take it out of the queue
+        for (auto it = Q.pending.begin(); it != Q.pending.end(); ++it) if (*it == &me) { Q.pending.erase(it); break; }
     }
     if (Q.pending.empty()) Q.leader = false;
     else Q.pending.front()->state.store(2, std::memory_order_release);      // leadership passes to the oldest waiter
     lk.unlock();
     Q.gen.fetch_add(1, std::memory_order_release);
     syscall(SYS_futex, reinterpret_cast<uint32_t *>(&Q.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    if (rc) g_err = err;
     return rc;
 }
 
@@ -1208,10 +1255,12 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_OCT_MAX: *value = c->oct_limit; return TFHE_OK;
     case TFHE_OPT_KS_MFMA_MIN: *value = c->ks_mfma_min; return TFHE_OK;
     case TFHE_OPT_FROZEN: *value = c->frozen ? 1 : 0; return TFHE_OK;
-    case TFHE_OPT_COMBINE_MAX: *value = c->combine_max; return TFHE_OK;
+    case TFHE_OPT_COMBINE_MAX: *value = c->combine_max.load(); return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT: *value = c->ks_wide_ct; return TFHE_OK;
-    case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)c->comb_launches; return TFHE_OK;
-    case TFHE_OPT_COMBINE_REQUESTS: *value = (int)c->comb_requests; return TFHE_OK;
+    case TFHE_OPT_CLONE_PATH: *value = c->clone_path; return TFHE_OK;
+    // the counters are 64-bit; the option interface is int: saturate instead of wrapping
+    case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)std::min<long long>(c->comb_launches.load(), INT_MAX); return TFHE_OK;
+    case TFHE_OPT_COMBINE_REQUESTS: *value = (int)std::min<long long>(c->comb_requests.load(), INT_MAX); return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);
     }
 }
@@ -1521,6 +1570,86 @@ int tfhe_key_import(tfhe_ctx *c, int which, const void *src, size_t bytes)
     return TFHE_OK;
 }
 
+// ---- one cloud key on several GPUs of a node, from ONE process (trgsw.go:234-252: the reference fans a batch out over goroutines
+// that share the read-only keys; here the keys are per device, so the fan-out needs a replica per GPU) -----------------------------
+// The replica is made GPU to GPU: the two device-layout keys travel by hipMemcpyPeerAsync (over xGMI when the devices are peers;
+// a plain device-to-device copy when source and target are the same GPU), and the target derives what a load derives (the
+// four-/eight-wave key layout, the byte-column key-switching key) on its own stream.  No host copy of the 147 MB (1.8 GB at the
+// Uint5 set) is ever made -- unless the devices are NOT peers (hipDeviceCanAccessPeer false): then the copy is staged through
+// page-locked host memory in 32 MB pieces, which is what tfhe_key_export + tfhe_key_import would do, minus the full-size host blob.
+namespace {
+constexpr size_t kCloneStage = (size_t)32 << 20;
+
+int peer_copy(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, bool peers, hipStream_t st, void *bounce)
+{
+    if (dst_dev == src_dev) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return TFHE_OK;
+    }
+    if (peers) {
+        HIP_TRY(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
+        return TFHE_OK;
+    }
+    for (size_t at = 0; at < bytes; at += kCloneStage) {      // documented fallback: no peer access between the two devices
+        const size_t len = bytes - at < kCloneStage ? bytes - at : kCloneStage;
+        HIP_TRY(hipMemcpy(bounce, static_cast<const char *>(src) + at, len, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(static_cast<char *>(dst) + at, bounce, len, hipMemcpyHostToDevice));
+    }
+    return TFHE_OK;
+}
+}
+
+int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out)
+{
+    if (!src || !out) return fail(TFHE_E_INVALID, "null argument");
+    *out = nullptr;
+    tfhe_ctx *dst = nullptr;
+    int rc = tfhe_ctx_create(&src->P, device_id, &dst);           // validates device_id; leaves device_id current
+    if (rc) return rc;
+    struct Guard {
+        tfhe_ctx *c;
+        ~Guard() { if (c) tfhe_ctx_destroy(c); }
+    } guard{dst};
+    std::lock_guard<std::recursive_mutex> lk(src->mu);            // no key load on the source while it is being read
+    // the per-context limits travel with the key: a clone dispatches like its source
+    dst->quad_limit = src->quad_limit; dst->oct_limit = src->oct_limit; dst->ks_mfma_min = src->ks_mfma_min;
+    dst->ks_wide_ct = src->ks_wide_ct; dst->combine_max = src->combine_max.load();
+    bool peers = false;
+    void *bounce = nullptr;
+    struct Bounce { void *&p; ~Bounce() { if (p) (void)hipHostFree(p); } } bounce_guard{bounce};
+    if (device_id != src->device) {
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, device_id, src->device));
+        if (can) {
+            hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);      // current device (the target) maps the source's memory
+            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            peers = e == hipSuccess;
+            if (!peers) (void)hipGetLastError();
+        }
+        if (!peers) HIP_TRY(hipHostMalloc(&bounce, kCloneStage, hipHostMallocDefault));
+    }
+    dst->clone_path = device_id == src->device ? 1 : peers ? 2 : 3;
+    hipStream_t st = dst->stream;
+    if (src->have_bsk) {
+        const size_t bytes = key_payload_bytes(src, 0);
+        if ((rc = dst->bsk.reserve(bytes))) return rc;
+        if ((rc = peer_copy(dst->bsk.p, device_id, src->bsk.p, src->device, bytes, peers, st, bounce))) return rc;
+        if ((rc = make_quad_key(dst, st))) return rc;
+    }
+    if (src->have_ksk) {
+        const size_t bytes = key_payload_bytes(src, 1);
+        if ((rc = dst->ksk.reserve(bytes))) return rc;
+        if ((rc = peer_copy(dst->ksk.p, device_id, src->ksk.p, src->device, bytes, peers, st, bounce))) return rc;
+        if ((rc = make_mfma_ksk(dst, st))) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    dst->have_bsk = src->have_bsk.load();
+    dst->have_ksk = src->have_ksk.load();
+    guard.c = nullptr;
+    *out = dst;
+    return TFHE_OK;
+}
+
 int tfhe_keygen_cloud(tfhe_ctx *c, const uint32_t *s0, const uint32_t *s1, double alpha_lv0, double alpha_lv1,
                       uint64_t seed)
 {
@@ -1689,7 +1818,7 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
         if (op_uniform < 0 || op_uniform > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d", op_uniform);
         if (op_uniform == TFHE_OP_MUX && !cc) return fail(TFHE_E_INVALID, "MUX needs the third operand");
     }
-    if (B > c->combine_max) return gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
+    if (B > c->combine_max || B > combine_cap(c, 0)) return gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
     tfhe_ctx::GateReq me{0, ops, op_uniform, a, b, cc, out, B};
     return combine_request(c, me);
 }

@@ -134,6 +134,13 @@ class CloudKey {
         return blob;
     }
     void Import(int which, const std::vector<uint8_t> &blob) { check(tfhe_key_import(ctx_, which, blob.data(), blob.size())); }
+    // a replica of this key on another GPU (or a second context on the same one), copied GPU to GPU: tfhe_ctx_clone_to
+    std::unique_ptr<CloudKey> CloneTo(int device) const
+    {
+        tfhe_ctx *c = nullptr;
+        check(tfhe_ctx_clone_to(ctx_, device, &c));
+        return std::unique_ptr<CloudKey>(new CloudKey(P, c));
+    }
     // an empty context of the given parameters, to Import a cloud key into
     static std::unique_ptr<CloudKey> Empty(const params::Params &p, int device = 0) { return std::make_unique<CloudKey>(p, nullptr, nullptr, device); }
     ~CloudKey() { if (ctx_) tfhe_ctx_destroy(ctx_); }
@@ -143,26 +150,29 @@ class CloudKey {
     params::Params P;
 
   private:
+    CloudKey(const params::Params &p, tfhe_ctx *adopted) : P(p), ctx_(adopted) {}      // CloneTo
     tfhe_ctx *ctx_ = nullptr;
 };
 
 // One cloud key on SEVERAL GPUs of a node, used from ONE process (a Go service: one goroutine per device instead of one
 // process per GPU; the reference's own concurrency is one evaluator per goroutine, trgsw.go:227-252).  The key is replicated
-// through the engine's blobs -- exported once from `src`, imported (header-checked) into an empty context per device -- and batch
-// calls shard contiguously, one thread per replica (gates::BatchOnSet below).  devices may repeat an index: two contexts on one
-// GPU are two independent submitters (that is how tests/cpp exercises this on a one-GPU box).
+// GPU to GPU behind the C ABI -- tfhe_ctx_clone_to: hipMemcpyPeerAsync between the device layouts, over xGMI between two GPUs,
+// a device-to-device copy on one; no host copy of the 147 MB (round 4 went through Export -> host blob -> Import per device) --
+// and batch calls shard contiguously, one thread per replica (gates::BatchOnSet below).  devices may repeat an index: two
+// contexts on one GPU are two independent submitters (that is how tests/cpp exercises this on a one-GPU box).
 class CloudKeySet {
   public:
     CloudKeySet(const CloudKey &src, const std::vector<int> &devices) : P(src.P)
     {
         if (devices.empty()) throw Panic(TFHE_E_INVALID, "CloudKeySet needs at least one device");
-        const std::vector<uint8_t> bsk = src.Export(0), ksk = src.Export(1);
-        for (int d : devices) {
-            auto ck = CloudKey::Empty(P, d);
-            ck->Import(0, bsk);
-            ck->Import(1, ksk);
-            replicas_.push_back(std::move(ck));
-        }
+        for (int d : devices) replicas_.push_back(src.CloneTo(d));
+    }
+    // how replica i's keys arrived (TFHE_OPT_CLONE_PATH): 1 same GPU, 2 peer copy (xGMI), 3 host-staged (devices are not peers)
+    int ClonePath(size_t i) const
+    {
+        int v = 0;
+        check(tfhe_ctx_get_option(replicas_[i]->ctx(), TFHE_OPT_CLONE_PATH, &v));
+        return v;
     }
     // every visible GPU once
     static std::vector<int> AllDevices()

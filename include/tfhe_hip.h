@@ -120,8 +120,11 @@ enum {
                                   (see tfhe_gate_batch); default (and -1) = one launch's worth, 0 = never                  */
     TFHE_OPT_COMBINE_LAUNCHES = 6,  /* read-only: combined launches issued so far ...                                       */
     TFHE_OPT_COMBINE_REQUESTS = 7,  /* ... and the tfhe_gate_batch calls they carried                                       */
-    TFHE_OPT_KS_WIDE_CT = 8    /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
+    TFHE_OPT_KS_WIDE_CT = 8,   /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
                                   only: one wave per SIMD, slower)                                                         */
+    TFHE_OPT_CLONE_PATH = 9    /* read-only: how tfhe_ctx_clone_to brought this context's keys here: 0 = not a clone, 1 = same
+                                  GPU (device-to-device copy), 2 = peer copy GPU to GPU (xGMI), 3 = staged through page-locked
+                                  host memory (the devices are not peers)                                                  */
 };
 int tfhe_ctx_set_option(tfhe_ctx *ctx, int option, int value);
 int tfhe_ctx_get_option(tfhe_ctx *ctx, int option, int *value);
@@ -174,6 +177,20 @@ int tfhe_key_import_dev(tfhe_ctx *ctx, int which, const void *d_src, size_t byte
 /* The same blobs through HOST memory: persist a GPU-generated cloud key, or hand it to another process; synchronous. */
 int tfhe_key_export(tfhe_ctx *ctx, int which, void *dst);
 int tfhe_key_import(tfhe_ctx *ctx, int which, const void *src, size_t bytes);
+
+/* A replica of `src` -- parameters, dispatch limits and whichever keys it holds -- on GPU device_id: the in-process form of
+ * "replicate the read-only keys, shard the batch" (trgsw.BatchBlindRotate fans a batch out over goroutines that SHARE the
+ * keys, trgsw.go:234-252; with one key copy per GPU the fan-out needs a replica per device first).  The keys travel GPU to
+ * GPU: hipMemcpyPeerAsync between the device layouts (xGMI when hipDeviceCanAccessPeer says the two are peers -- peer access
+ * is enabled on the target for the source), a plain device-to-device copy when device_id is the source's own GPU (two
+ * contexts on one GPU are two independent submitters); the target then derives what a key load derives.  No host copy of the
+ * keys is made.  Fallback when the devices are NOT peers: the copy is staged through 32 MB of page-locked host memory
+ * (what tfhe_key_export + tfhe_key_import do, without the full-size host blob).  TFHE_OPT_CLONE_PATH on the new context
+ * says which of the three happened.  Synchronous; the source may be used by other threads meanwhile (its keys are immutable
+ * after load; key loads on it wait).  The replica is an ordinary context: tfhe_ctx_destroy it.  One goroutine / thread per
+ * replica, contiguous shards, results in index order is all the multi-GPU form of gates.Batch* needs (SURVEY.md 8e;
+ * shim/go/gpu: CloudKeySet, go-tfhe_amd/host/tfhe_gpu.hpp: cloudkey::CloudKeySet). */
+int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out);
 
 /* Evaluator.BootstrapAssign / BootstrapLUTAssign over a batch (evaluator.go:139-148,
  * programmable_bootstrap.go:93-115; batch fan-out trgsw.go:234-252).

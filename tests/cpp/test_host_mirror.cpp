@@ -82,11 +82,22 @@ int main()
         EXPECT(dec(r_xnor[i]) == (A[i] == B[i]), "BatchXNOR %d", i);
     }
     // one cloud key on several devices from ONE process (here: two contexts on the one GPU of the box): the key
-    // travels as header-checked blobs, the batch is sharded contiguously over one thread per replica, and every output word
-    // equals the single-context result
+    // is replicated GPU to GPU behind the C ABI (tfhe_ctx_clone_to; on one GPU the peer copy degenerates to a device-to-device
+    // copy: clone path 1), the batch is sharded contiguously over one thread per replica, and every output word equals the
+    // single-context result
     {
         cloudkey::CloudKeySet set(ck, {0, 0});
         EXPECT(set.size() == 2 && cloudkey::CloudKeySet::AllDevices().size() >= 1, "CloudKeySet");
+        EXPECT(set.ClonePath(0) == 1 && set.ClonePath(1) == 1, "clones onto the source's own GPU must take the device-to-device path");
+        {
+            // a clone is a full, independent context: its scalar gate equals the source's, word for word, and it outlives nothing
+            auto solo = ck.CloneTo(0);
+            auto x = enc(1), y = enc(0);
+            EXPECT(gates::NAND(x, y, *solo).P == gates::NAND(x, y, ck).P, "a clone's NAND differs from its source's");
+            bool bad = false;
+            try { (void)ck.CloneTo(4096); } catch (const Panic &) { bad = true; }
+            EXPECT(bad, "cloning onto a device that does not exist must panic");
+        }
         gates::Pairs seven;
         std::vector<std::array<gates::Ciphertext, 3>> mux7;
         for (int i = 0; i < 7; i++) {                        // ragged: shards of 3 and 4

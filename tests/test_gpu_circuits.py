@@ -357,3 +357,75 @@ def test_sync_waits_for_every_stream_even_destroyed_ones(pkg, keys_small):
     for o in outs:
         assert np.array_equal(k.dec(o.cpu().numpy().view(np.uint32)), np.array(bits, bool))
     ck.close()
+
+
+def test_two_executors_on_one_context_release_is_refcounted_and_threads_run_on_a_frozen_context(pkg, keys_small):
+    """ADVICE r04: (i) release() of one executor must not un-freeze a context another executor's graph still replays on;
+    (ii) a second capture that does not fit the frozen buffers fails with an error naming max_instances; (iii) threads issuing
+    scalar gates on a frozen context get what lone calls return -- the combiner re-issues a batch one by one when only the
+    COMBINATION needs buffers the frozen context may not grow."""
+    import threading
+    import torch
+    from go_tfhe_amd.circuits import ripple_carry_adder, adder_constant_wire, CircuitExecutor
+    k = keys_small
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    ctx = ck.ctx
+    bits, C = 2, 2
+    levels, n_wires, sums, cout = ripple_carry_adder(bits, fold_carry_in=False)
+    n1 = k.p.n + 1
+    wires = np.zeros((n_wires, C, n1), np.uint32)
+    av, bv = np.array([1, 2]), np.array([3, 1])
+    for i in range(bits):
+        wires[i] = k.enc((av >> i) & 1)
+        wires[bits + i] = k.enc((bv >> i) & 1)
+    wires[adder_constant_wire(bits)] = pkg.gates.Constant(False, k.p)
+    wt1 = torch.from_numpy(wires.view(np.int32)).cuda()
+    wt2 = wt1.clone()
+    ex1, ex2 = CircuitExecutor(ctx, levels, n_wires), CircuitExecutor(ctx, levels, n_wires)
+    g1 = ex1.capture(wt1)
+    g2 = ex2.capture(wt2)                                   # same size: fits the frozen buffers
+    assert ctx.get_option("frozen") == 1 and ctx._graphs_alive == 2
+    # (ii) a much wider capture on the frozen context: refused, and the message names the remedy
+    wide = torch.from_numpy(np.zeros((n_wires, 4096, n1), np.int32)).cuda()
+    with pytest.raises(RuntimeError, match="max_instances"):
+        CircuitExecutor(ctx, levels, n_wires).capture(wide)
+    del wide
+    # (iii) 64 threads x scalar gates on the frozen context: the reserved scratch holds a handful of bootstraps, the combined
+    # total would need more -> every caller must still get the lone-call result, none a 'frozen' error
+    rs = np.random.RandomState(3)
+    a = rs.randint(0, 2**32, size=(64, n1), dtype=np.uint64).astype(np.uint32)
+    b = rs.randint(0, 2**32, size=(64, n1), dtype=np.uint64).astype(np.uint32)
+    ctx.set_option("combine_max", 0)
+    want = [ctx.gate_batch("NAND", a[i:i + 1], b[i:i + 1]) for i in range(64)]
+    ctx.set_option("combine_max", -1)
+    got, errs = [None] * 64, []
+    gate = threading.Barrier(64)
+
+    def run(i):
+        gate.wait()
+        try:
+            for _ in range(3):
+                got[i] = ctx.gate_batch("NAND", a[i:i + 1], b[i:i + 1])
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(64)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not errs, errs[:3]
+    assert all(np.array_equal(got[i], want[i]) for i in range(64))
+    # (i) refcount: releasing ex1 leaves the context frozen for ex2's graph, which still replays correctly
+    del g1
+    ex1.release()
+    assert ctx.get_option("frozen") == 1 and ctx._graphs_alive == 1
+    g2.replay()
+    torch.cuda.synchronize()
+    res = wt2.cpu().numpy().view(np.uint32)
+    val = sum(k.dec(res[w]).astype(np.int64) << i for i, w in enumerate(sums)) + (k.dec(res[cout]).astype(np.int64) << bits)
+    assert np.array_equal(val, av + bv)
+    del g2
+    ex2.release()
+    assert ctx.get_option("frozen") == 0 and ctx._graphs_alive == 0
+    ck.close()

@@ -291,3 +291,41 @@ def test_concurrent_programmable_bootstraps_are_combined_and_bit_identical(oracl
         assert dec == [int((fa * m + fb) % modulus) for m in msgs]
     finally:
         ck.close()
+
+
+def test_combined_gates_at_a_tolerance_regime_shape_equal_lone_calls(oracle, pkg):
+    # at the shapes whose transforms are not exact (here Uint1: N = 1024, L = 2, Bgbit = 10) kernels of different
+    # launch shapes round differently, so a combined GATE launch -- like a combined table bootstrap -- must stay within the
+    # kernel shape a lone small call runs (at most one bootstrap per CU, within the four-/eight-wave limits): every caller's
+    # words equal the same call issued alone with combining switched off, even when far more gates than CUs are in flight.
+    from conftest import KeySet, gpu_params
+    k = KeySet(oracle, "uint1", 0x7F4E0071, n_override=24, torus=False)
+    ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
+    try:
+        ctx = ck.ctx
+        n1 = k.p.n + 1
+        rs = np.random.RandomState(17)
+        T = 96                                          # x 5 gates = 480 > the 256 CUs: more than one lone-shape launch
+        reqs = [(rs.randint(0, 2**32, size=(5, n1), dtype=np.uint64).astype(np.uint32),
+                 rs.randint(0, 2**32, size=(5, n1), dtype=np.uint64).astype(np.uint32)) for _ in range(T)]
+        ctx.set_option("combine_max", 0)
+        want = [ctx.gate_batch("XOR", a, b) for a, b in reqs]
+        ctx.set_option("combine_max", -1)
+        before = ctx.get_option("combine_requests")
+        got = [None] * T
+        gate = threading.Barrier(T)
+
+        def run(i):
+            gate.wait()
+            got[i] = ctx.gate_batch("XOR", *reqs[i])
+
+        ts = [threading.Thread(target=run, args=(i,)) for i in range(T)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i in range(T):
+            assert np.array_equal(got[i], want[i]), f"request {i}: a combined launch left the lone call's kernel shape"
+        assert ctx.get_option("combine_requests") > before
+    finally:
+        ck.close()
