@@ -1,0 +1,203 @@
+"""CPU tier: the Go side of the boundary (shim/go/**) checked WITHOUT a Go toolchain.
+
+The image has no `go`, so the shim cannot be compiled here.  tools/go_static/gocheck.py parses it together with the
+top-level declarations of every reference package (read from /root/reference: the test skips where that is absent, e.g. on
+the GPU box) and the C header, infers the type of every expression and reports what `go build` would refuse in the places a
+cgo shim goes wrong.  This file holds the shim to it, proves the checker is not vacuous (mutations of the shim and round 4's
+defective text must be caught, with the expected messages), and keeps INTEGRATION.md's blocks equal to the files."""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+HDR = os.path.join(ROOT, "include", "tfhe_hip.h")
+SHIM = os.path.join(ROOT, "shim", "go")
+sys.path.insert(0, os.path.join(ROOT, "tools", "go_static"))
+
+needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gates")), reason="/root/reference is absent (GPU box): nothing to resolve the shim against")
+
+
+def _read(rel):
+    with open(os.path.join(ROOT, rel)) as fh:
+        return fh.read()
+
+
+def _check_sources(files):
+    """files: {import path: [(fname, src)]} checked as packages of their own (the in-tree shim is not loaded)."""
+    import gocheck
+    return gocheck.check_shim(REF, HDR, None, extra_sources=files)[0]
+
+
+def _shim_sources(mutate=None):
+    """The three shim packages as extra_sources, optionally with one file's text mutated: {rel path: (old, new)}."""
+    mod = "github.com/thedonutfactory/go-tfhe-gpu"
+    out = {}
+    for d, fname in (("gpu", "gpu.go"), ("gates", "gates_gpu.go"), ("evaluator", "evaluator_gpu.go")):
+        rel = f"shim/go/{d}/{fname}"
+        src = _read(rel)
+        if mutate and rel in mutate:
+            old, new = mutate[rel]
+            assert src.count(old) >= 1, f"mutation anchor {old!r} not found in {rel}"
+            src = src.replace(old, new, 1)
+        out[f"{mod}/{d}"] = [(rel, src)]
+    return out
+
+
+@needs_ref
+def test_shim_type_checks_against_the_reference_and_the_c_header():
+    import gocheck
+    errs, stats = gocheck.check_shim(REF, HDR, SHIM)
+    assert not errs, "\n".join(errs)
+    assert stats["files"] >= 4 and stats["funcs"] >= 80 and stats["reference_packages"] >= 12, stats
+
+
+@needs_ref
+def test_checker_resolved_the_reference_declarations_the_shim_relies_on():
+    # the facts the shim depends on are READ from the reference sources, not assumed: if upstream renames a field or changes a
+    # type, this test says so before any Go compiler does
+    import gocheck
+    w, ref = gocheck.build_world(REF, HDR)
+    for p in ref:
+        w.resolve_package(p, strict=False)
+    mod = "github.com/thedonutfactory/go-tfhe"
+    P = lambda name: w.by_path[f"{mod}/{name}"]                                   # noqa: E731
+    torus = ("named", f"{mod}/params.Torus")
+    assert P("params").types["Torus"] == ("defined", ("basic", "uint32"))          # params/params.go:27: a DEFINED type
+    g = dict(P("params").types["TRGSWLv1Params"][1][1])
+    assert g["N"] == g["NBIT"] == g["L"] == g["BASEBIT"] == g["IKS_T"] == ("basic", "int")
+    assert g["BGBIT"] == g["BG"] == ("basic", "uint32")
+    assert dict(P("tlwe").types["TLWELv0"][1][1]) == {"P": ("slice", torus)}
+    assert dict(P("trlwe").types["TRLWELv1"][1][1]) == {"A": ("slice", torus), "B": ("slice", torus)}
+    assert dict(P("poly").types["FourierPoly"][1][1]) == {"Coeffs": ("slice", ("basic", "float64"))}
+    assert dict(P("trgsw").types["TRGSWLv1FFT"][1][1]) == {"TRLWEFFT": ("slice", ("named", f"{mod}/trgsw.TRLWELv1FFT"))}
+    fp = ("named", f"{mod}/poly.FourierPoly")
+    assert dict(P("trgsw").types["TRLWELv1FFT"][1][1]) == {"A": fp, "B": fp}
+    ck = dict(P("cloudkey").types["CloudKey"][1][1])
+    assert ck["KeySwitchingKey"] == ("slice", ("ptr", ("named", f"{mod}/tlwe.TLWELv0")))
+    assert ck["BootstrappingKey"] == ("slice", ("ptr", ("named", f"{mod}/trgsw.TRGSWLv1FFT")))
+    assert ck["DecompositionOffset"] == torus
+    assert dict(P("key").types["SecretKey"][1][1]) == {"KeyLv0": ("slice", torus), "KeyLv1": ("slice", torus)}
+    assert dict(P("lut").types["LookUpTable"][1][1]) == {"Poly": ("ptr", ("named", f"{mod}/trlwe.TRLWELv1"))}
+    assert P("gates").types["Ciphertext"] == ("alias", ("named", f"{mod}/tlwe.TLWELv0"))
+
+
+@needs_ref
+def test_shim_keeps_the_reference_signatures():
+    """gates.* (14 scalar + 6 batch, gates/gates.go:26-126,156-312) and the evaluator's bootstrap surface
+    (evaluator/evaluator.go:110-157, evaluator/programmable_bootstrap.go:16-115, evaluator/gates_helper.go:10-63): every
+    function of the reference exists in the shim with an IDENTICAL signature (after alias resolution)."""
+    import gocheck
+    w, ref = gocheck.build_world(REF, HDR)
+    shim = {}
+    for d in ("gpu", "gates", "evaluator"):
+        shim[d], _ = w.load_package(f"github.com/thedonutfactory/go-tfhe-gpu/{d}", gocheck.read_dir(os.path.join(SHIM, d)), name_hint=d, bodies=False)
+    for p in ref:
+        w.resolve_package(p, strict=False)
+    for p in shim.values():
+        w.resolve_package(p)
+    assert not w.errors, w.errors
+    rg, re_ = w.by_path["github.com/thedonutfactory/go-tfhe/gates"], w.by_path["github.com/thedonutfactory/go-tfhe/evaluator"]
+    scalar = ["NAND", "OR", "AND", "XOR", "XNOR", "Constant", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX", "NOT", "Copy"]
+    batch = ["BatchNAND", "BatchAND", "BatchOR", "BatchXOR", "BatchNOR", "BatchXNOR"]
+    for name in scalar + batch:
+        assert name in rg.funcs, f"reference gates.{name} not found"
+        assert name in shim["gates"].funcs, f"shim gates.{name} missing"
+        assert w.dealias(shim["gates"].funcs[name]) == w.dealias(rg.funcs[name]), \
+            f"gates.{name}: shim {gocheck.tstr(w.dealias(shim['gates'].funcs[name]))} vs reference {gocheck.tstr(w.dealias(rg.funcs[name]))}"
+    assert w.dealias(("named", "github.com/thedonutfactory/go-tfhe-gpu/gates.Ciphertext")) == ("named", "github.com/thedonutfactory/go-tfhe/tlwe.TLWELv0")
+    methods = ["BlindRotateAssign", "BootstrapAssign", "Bootstrap", "BootstrapLUTAssign", "BootstrapLUT", "BootstrapLUTTemp", "BootstrapFunc",
+               "BootstrapFuncAssign", "PrepareNAND", "PrepareAND", "PrepareOR", "PrepareXOR"]
+    for m in methods:
+        assert ("Evaluator", m) in re_.methods, f"reference Evaluator.{m} not found"
+        assert ("Evaluator", m) in shim["evaluator"].methods, f"shim Evaluator.{m} missing"
+        assert w.dealias(shim["evaluator"].methods[("Evaluator", m)]) == w.dealias(re_.methods[("Evaluator", m)]), f"Evaluator.{m}: signature differs"
+    # NewEvaluator / ShallowCopy differ only in the Evaluator type they return
+    assert shim["evaluator"].funcs["NewEvaluator"][1] == re_.funcs["NewEvaluator"][1] == (("basic", "int"),)
+
+
+@needs_ref
+def test_round4_shim_text_is_rejected_at_exactly_its_three_torus_crossings():
+    src = _read("tests/golden/go_shim_r04_defective.go.txt")
+    errs = _check_sources({"example.com/r04/gpu": [("r04_gpu.go", src)]})
+    assert len(errs) == 3, errs
+    lines = src.splitlines()
+    sites = sorted(lines[int(re.search(r":(\d+):", e).group(1)) - 1].strip() for e in errs)
+    assert sites == sorted(["ksk = append(ksk, row.P...)", "flat = append(flat, c.P...)",
+                            "res[i] = &tlwe.TLWELv0{P: out[i*n1 : (i+1)*n1 : (i+1)*n1]}"]), sites
+    assert all("params.Torus" in e and "uint32" in e for e in errs)
+
+
+MUTATIONS = [
+    # (file, old, new, expected message fragment)
+    ("shim/go/gpu/gpu.go", "row.A.Coeffs...", "row.A.Coefs...", "has no field or method Coefs"),
+    ("shim/go/gpu/gpu.go", "g := params.GetTRGSWLv1()\n\tl0", "g := params.GetTRGSWLv2()\n\tl0", "undefined: params.GetTRGSWLv2"),
+    ("shim/go/gpu/gpu.go", "t: C.int32_t(g.IKS_T)", "t: C.int32_t(g.IKST)", "has no field or method IKST"),
+    ("shim/go/gpu/gpu.go", "check(C.tfhe_ctx_create(&p, C.int(device), &k.ctx))", "check(C.tfhe_ctx_create(&p, device, &k.ctx))", "cannot use int as C.int"),
+    ("shim/go/gpu/gpu.go", "check(C.tfhe_load_ksk(k.ctx, torusPtr(rows)))", "check(C.tfhe_load_ksk(k.ctx, torusPtr(rows), 0))", "argument(s) for 2 parameter(s)"),
+    ("shim/go/gpu/gpu.go", "rows := make([]params.Torus, 0, len(ksk)*k.n1)", "rows := make([]uint32, 0, len(ksk)*k.n1)", "in append"),
+    ("shim/go/gpu/gpu.go", "check(C.tfhe_key_size(k.ctx, C.int(which), &n))", "check(C.tfhe_key_sizes(k.ctx, C.int(which), &n))", "undefined: C.tfhe_key_sizes"),
+    ("shim/go/gpu/gpu.go", "flat := make([]float64, 0, len(bsk)*2*g.L*2*g.N)", "flat := make([]float32, 0, len(bsk)*2*g.L*2*g.N)", "in append"),
+    ("shim/go/gpu/gpu.go", "\treturn unflatten(out, k.n1)\n}\n\n// GateBatchOps", "\treturn out\n}\n\n// GateBatchOps", "in return value"),
+    ("shim/go/gpu/gpu.go", "\t\"github.com/thedonutfactory/go-tfhe/key\"\n", "\t\"github.com/thedonutfactory/go-tfhe/key\"\n\t\"github.com/thedonutfactory/go-tfhe/utils\"\n", "imported and not used"),
+    ("shim/go/gpu/gpu.go", "\tfa := flatten(a, k.n1)\n\tfb := flatten(b, k.n1)\n\tvar fc []params.Torus\n\tif c != nil {\n\t\tfc = flatten(c, k.n1)\n\t}\n\tout := make([]params.Torus, len(fa))\n\tlocked(func() {\n\t\tcheck(C.tfhe_gate_batch(k.ctx, nil,",
+     "\tfa := flatten(a, k.n1)\n\tspare := 1\n\tfb := flatten(b, k.n1)\n\tvar fc []params.Torus\n\tif c != nil {\n\t\tfc = flatten(c, k.n1)\n\t}\n\tout := make([]params.Torus, len(fa))\n\tlocked(func() {\n\t\tcheck(C.tfhe_gate_batch(k.ctx, nil,", "spare declared and not used"),
+    ("shim/go/gpu/gpu.go", "sk.KeyLv0), torusPtr(sk.KeyLv1)", "sk.KeyLv0), torusPtr(sk.KeyLvl1)", "has no field or method KeyLvl1"),
+    ("shim/go/gates/gates_gpu.go", "return gpu.Attached(ck.BootstrappingKey, ck.KeySwitchingKey)", "return gpu.Attached(ck.KeySwitchingKey, ck.BootstrappingKey)", "cannot use"),
+    ("shim/go/gates/gates_gpu.go", "return gate(gpu.OpNAND, tlweA, tlweB, ck)", "return gate(gpu.OpNANDS, tlweA, tlweB, ck)", "undefined: gpu.OpNANDS"),
+    ("shim/go/gates/gates_gpu.go", "\tresult.SetB(mu)\n", "\tresult.SetB(0.125)\n", "cannot use untyped float"),
+    ("shim/go/evaluator/evaluator_gpu.go", "e.BootstrapAssign(ctIn, lut.Poly, bsk, ksk, decompositionOffset, ctOut)", "e.BootstrapAssign(ctIn, lut, bsk, ksk, decompositionOffset, ctOut)", "cannot use"),
+    ("shim/go/evaluator/evaluator_gpu.go", "copy(ctOut.P, res[0].P)", "copy(ctOut.P, res[0].A)", "has no field or method A"),
+    ("shim/go/evaluator/evaluator_gpu.go", "lookupTable := generator.GenLookUpTable(f)\n\treturn", "lookupTable := generator.GenLookupTable(f)\n\treturn", "has no field or method GenLookupTable"),
+]
+
+
+@needs_ref
+@pytest.mark.parametrize("case", MUTATIONS, ids=[f"{i}:{m[3][:28]}" for i, m in enumerate(MUTATIONS)])
+def test_checker_catches_a_seeded_defect(case):
+    rel, old, new, frag = case
+    errs = _check_sources(_shim_sources({rel: (old, new)}))
+    assert errs, f"mutation {old!r} -> {new!r} in {rel} was not noticed"
+    assert any(frag in e for e in errs), (frag, errs)
+
+
+def test_integration_md_shows_the_shim_files_verbatim():
+    import sync_integration_md as sync
+    doc = _read("INTEGRATION.md")
+    found = dict(sync.blocks(doc))
+    for rel in ("shim/go/gpu/gpu.go", "shim/go/gates/gates_gpu.go", "shim/go/evaluator/evaluator_gpu.go"):
+        assert rel in found, f"INTEGRATION.md has no block for {rel}"
+        assert found[rel] == sync.render(rel), f"INTEGRATION.md's block for {rel} differs from the file: run python tools/go_static/sync_integration_md.py"
+
+
+def test_shim_calls_every_entry_point_with_the_declared_argument_count():
+    # independent of gocheck (and of /root/reference): every C.tfhe_* call in the shim names a declared entry point and passes the
+    # declared number of arguments (the lint round 4 ran on the markdown block, now on the files)
+    hdr = open(HDR).read()
+    decl = {}
+    for m in re.finditer(r"^(?:int|const char \*)\s*\*?(tfhe_\w+)\(([^;]*?)\);", hdr, re.M | re.S):
+        args = [a.strip() for a in re.sub(r"\s+", " ", m.group(2)).split(",") if a.strip() and a.strip() != "void"]
+        decl[m.group(1)] = len(args)
+    go = _read("shim/go/gpu/gpu.go")
+    calls = set()
+    for m in re.finditer(r"C\.(tfhe_\w+)\(", go):
+        name, i, depth = m.group(1), m.end(), 1
+        j = i
+        while depth:
+            depth += go[j] == "("
+            depth -= go[j] == ")"
+            j += 1
+        body, d = go[i:j - 1], 0
+        n = 1 if body.strip() else 0
+        for ch in body:
+            d += ch in "(["
+            d -= ch in ")]"
+            n += ch == "," and d == 0
+        assert name in decl, f"gpu.go calls undeclared {name}"
+        assert n == decl[name], f"{name}: shim passes {n} arguments, header declares {decl[name]}"
+        calls.add(name)
+    assert len(calls) >= 15, sorted(calls)
+    for other in ("shim/go/gates/gates_gpu.go", "shim/go/evaluator/evaluator_gpu.go"):
+        assert 'import "C"' not in _read(other), f"{other} must not touch cgo: package gpu is the only cgo layer"

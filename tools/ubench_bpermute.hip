@@ -79,21 +79,23 @@ __device__ __forceinline__ void xchg1_lds(cd (&x)[8], cd *sc, int lane)
 //    -> lane (s, lo) holds in y[j] its x[(j + s) & 7]
 // 2. z[j] at lane (hi, lo) = y[j] of lane ((hi - j) & 7, lo) = x[hi] of that lane   (one bpermute per register dword: 32)
 // 3. new x[b] = z[(hi - b) & 7]: rotate by -hi with index reversal                  (3 stages of selects + a static reversal)
+template <int S> __device__ __forceinline__ void rot_stage(cd (&x)[8], bool take)      // x[j] <- take ? x[(j + S) & 7] : x[j]
+{
+    cd y[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const double are = x[(j + S) & 7].re, aim = x[(j + S) & 7].im, bre = x[j].re, bim = x[j].im;   // values first: a select of
+        y[j].re = take ? are : bre;                                                                    // ADDRESSES would send the
+        y[j].im = take ? aim : bim;                                                                    // array to scratch
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = y[j];
+}
 __device__ __forceinline__ void rot_by(cd (&x)[8], int amount)                     // x[j] <- x[(j + amount) & 7], amount per lane
 {
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const bool take = (amount >> s) & 1;
-        cd y[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const cd &o = x[(j + (1 << s)) & 7];
-            y[j].re = take ? o.re : x[j].re;
-            y[j].im = take ? o.im : x[j].im;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = y[j];
-    }
+    rot_stage<1>(x, amount & 1);
+    rot_stage<2>(x, amount & 2);
+    rot_stage<4>(x, amount & 4);
 }
 __device__ __forceinline__ void xchg1_bperm(cd (&x)[8], int lane)
 {
@@ -103,10 +105,10 @@ __device__ __forceinline__ void xchg1_bperm(cd (&x)[8], int lane)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const int srcl = (((hi - j) & 7) << 3) | lo;
-        U a, b; a.c = x[j];
-#pragma unroll
-        for (int i = 0; i < 4; i++) b.w[i] = (unsigned)__builtin_amdgcn_ds_bpermute(srcl * 4, (int)a.w[i]);
-        z[j] = b.c;
+        const int a0 = __double2loint(x[j].re), a1 = __double2hiint(x[j].re), a2 = __double2loint(x[j].im), a3 = __double2hiint(x[j].im);
+        const int b0 = __builtin_amdgcn_ds_bpermute(srcl * 4, a0), b1 = __builtin_amdgcn_ds_bpermute(srcl * 4, a1);
+        const int b2 = __builtin_amdgcn_ds_bpermute(srcl * 4, a2), b3 = __builtin_amdgcn_ds_bpermute(srcl * 4, a3);
+        z[j] = cd{__hiloint2double(b1, b0), __hiloint2double(b3, b2)};
     }
     // new x[b] = z[(hi - b) & 7] = zr[(b - hi) & 7] with zr[j] = z[(8 - j) & 7]  -> rotate zr by (-hi) & 7
     cd zr[8];
@@ -122,6 +124,7 @@ template <int MODE> __global__ __launch_bounds__(512) void k_x(double *out, int 
     __shared__ cd sc[8][8 * 72];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     cd x[8]; double y[8];
+#pragma unroll
     for (int i = 0; i < 8; i++) { x[i] = cd{(double)(lane * 8 + i), (double)(1000 + lane * 8 + i)}; y[i] = lane + i; }
     if (MODE == 9) {
         cd a[8], b[8];
@@ -145,6 +148,7 @@ template <int MODE> __global__ __launch_bounds__(512) void k_x(double *out, int 
         }
     }
     double s = 0;
+#pragma unroll
     for (int i = 0; i < 8; i++) s += x[i].re + x[i].im + y[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
