@@ -22,6 +22,16 @@ need_small = pytest.mark.skipif(not have_small, reason="parity unpinned: no Go-g
                                                        "(tools/go_golden/main.go needs a Go toolchain)")
 need_big = pytest.mark.skipif(not (have_small and have_big), reason="parity unpinned: no full-key Go vectors ($TFHE_GO_GOLDEN_BIG)")
 
+# the programmable-bootstrap seam (BASELINE config 4): exact-integer lookup tables in small/, a full Uint5 key + bootstraps in big/uint5
+BIG5 = os.environ.get("TFHE_GO_GOLDEN_BIG_UINT5", os.path.join(BIG, "uint5"))
+have_small5 = os.path.exists(os.path.join(SMALL, "uint5_lut_identity.npy"))
+have_big5 = os.path.exists(os.path.join(BIG5, "pbs_out.npy"))
+need_small5 = pytest.mark.skipif(not have_small5, reason="parity unpinned: no Go-generated Uint5 lookup tables in tests/golden/go "
+                                                         "(tools/go_golden/main.go needs a Go toolchain)")
+need_big5 = pytest.mark.skipif(not (have_small5 and have_big5), reason="parity unpinned: no full-key Uint5 Go vectors ($TFHE_GO_GOLDEN_BIG/uint5)")
+LUT_FUNCS = {"identity": lambda x: x, "mod16": lambda x: x % 16, "ge16": lambda x: int(x >= 16)}      # examples/add_two_numbers/main.go:59-72
+LUT_ORDER = ["identity", "mod16", "ge16"]
+
 GATES2 = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
 
 
@@ -111,4 +121,63 @@ def test_gpu_bootstrap_and_gates_equal_go(oracle, pkg):
     for op in GATES2:
         assert np.array_equal(ck.ctx.gate_batch(op, a, b), load(BIG, "gate_" + op)), op
     assert np.array_equal(ck.ctx.gate_batch("MUX", a, b, c), load(BIG, "gate_MUX"))
+    ck.close()
+
+
+# ------------------------------------------------------------------------------- the programmable-bootstrap seam (Uint5)
+def go_params_uint5(oracle):
+    n, N, Nbit, L, Bgbit, basebit, t, offset, modulus = (int(x) for x in load(SMALL, "uint5_params"))
+    p = oracle.params("uint5")
+    assert (p.N, p.Nbit, p.L, p.Bgbit, p.basebit, p.t) == (N, Nbit, L, Bgbit, basebit, t)
+    if n != p.n:                                          # tools/go_golden/schema_selfcheck.py writes a reduced-n key
+        p = p.small(n)
+    assert oracle.offset(p) == offset and modulus == 32
+    return p, modulus
+
+
+@need_small5
+def test_lut_generators_equal_go_bit_for_bit(oracle, pkg):
+    # lut.Generator.GenLookUpTableAssign (lut/generator.go:56-100) is exact integer arithmetic: the oracle's generator and the
+    # host mirror's (go-tfhe_amd/lut.py) must reproduce the Go tables word for word
+    from go_tfhe_amd.lut import Generator
+    p, m = go_params_uint5(oracle)
+    for name, f in LUT_FUNCS.items():
+        want = load(SMALL, "uint5_lut_" + name)
+        assert want.shape == (2, p.N) and not want[0].any()
+        assert np.array_equal(oracle.lut_generate(p, [f(x) for x in range(m)]), want), name
+        assert np.array_equal(Generator(p, m).GenLookUpTable(f).poly, want), name
+
+
+def _check_pbs_outputs(oracle, p, m, s0, outs, msgs, which, go_dec):
+    """Tolerance regime: same decryption as the Go run and as f(m), and the output phase within 2^32/(4*32) of
+    the ideal encoding f(m) * 2^31/32 -- ciphertext words are not comparable across FFT implementations at this shape."""
+    scale = (1 << 31) // m
+    for i, row in enumerate(outs):
+        want = LUT_FUNCS[LUT_ORDER[int(which[i])]](int(msgs[i]))
+        assert oracle.decrypt_message(p, m, s0, row) == want == int(go_dec[i]), i
+        d = (int(oracle.phase(p, s0, row)) - want * scale) & 0xFFFFFFFF
+        assert min(d, (1 << 32) - d) < (1 << 32) // (4 * m), (i, d)
+
+
+@need_big5
+def test_oracle_programmable_bootstrap_agrees_with_go(oracle):
+    p, m = go_params_uint5(oracle)
+    bsk, ksk, s0 = load(BIG5, "bsk_fourier"), load(BIG5, "ksk"), load(BIG5, "key_lv0")
+    ins, msgs, which = load(BIG5, "pbs_in"), load(BIG5, "pbs_msgs"), load(BIG5, "pbs_lut")
+    _check_pbs_outputs(oracle, p, m, s0, load(BIG5, "pbs_out"), msgs, which, load(BIG5, "pbs_dec"))      # the Go outputs themselves
+    k = min(2, len(ins))                                  # ~0.1 s each on one core at full n
+    outs = [oracle.bootstrap(p, bsk, ksk, ins[i], load(SMALL, "uint5_lut_" + LUT_ORDER[int(which[i])])) for i in range(k)]
+    _check_pbs_outputs(oracle, p, m, s0, outs, msgs[:k], which[:k], load(BIG5, "pbs_dec")[:k])
+
+
+@pytest.mark.gpu
+@need_big5
+def test_gpu_programmable_bootstrap_agrees_with_go(oracle, pkg):
+    from conftest import gpu_params
+    p, m = go_params_uint5(oracle)
+    ck = pkg.CloudKey(gpu_params(pkg, p), bsk_fourier=load(BIG5, "bsk_fourier"), ksk=load(BIG5, "ksk"))
+    ins, msgs, which = load(BIG5, "pbs_in"), load(BIG5, "pbs_msgs"), load(BIG5, "pbs_lut")
+    tabs = np.stack([load(SMALL, "uint5_lut_" + LUT_ORDER[int(w)]) for w in which])
+    outs = ck.ctx.bootstrap_batch(ins, tabs)              # one table per item
+    _check_pbs_outputs(oracle, p, m, load(BIG5, "key_lv0"), outs, msgs, which, load(BIG5, "pbs_dec"))
     ck.close()

@@ -163,6 +163,23 @@ def test_checker_catches_a_seeded_defect(case):
     assert any(frag in e for e in errs), (frag, errs)
 
 
+@needs_ref
+def test_go_golden_program_type_checks():
+    # tools/go_golden/main.go (the program that will pin parity the day someone has Go) against the reference's declarations:
+    # every reference function it calls exists with those argument types.  The standard library is not modelled (lenient).
+    import gocheck
+    src = _read("tools/go_golden/main.go")
+    errs, _ = gocheck.check_shim(REF, HDR, None, extra_sources={"example.com/cmd/go_golden": [("tools/go_golden/main.go", src)]}, lenient_std=True)
+    assert not errs, "\n".join(errs)
+    for needle in ("gen.GenLookUpTableAssign(f, tables[i])", "eval.BootstrapLUTAssign(ins[i], tables[w], ck.BootstrappingKey, ck.KeySwitchingKey, ck.DecompositionOffset, outs[i])",
+                   "eval.BootstrapAssign(", "eval.ExternalProductAssign(", "gates.MUX("):
+        assert needle in src, needle
+    # and a seeded defect in it is caught
+    bad = src.replace("gen.GenLookUpTableAssign(f, tables[i])", "gen.GenLookUpTableAssign(tables[i], f)")
+    errs, _ = gocheck.check_shim(REF, HDR, None, extra_sources={"example.com/cmd/go_golden": [("main.go", bad)]}, lenient_std=True)
+    assert any("cannot use" in e for e in errs), errs
+
+
 def test_integration_md_shows_the_shim_files_verbatim():
     import sync_integration_md as sync
     doc = _read("INTEGRATION.md")

@@ -31,6 +31,25 @@
 //	  gate_a.npy, gate_b.npy, gate_c.npy   uint32 [B][n+1]; gate_bits.npy uint8 [3][B]
 //	  gate_<OP>.npy              uint32 [B][n+1]      gates.<OP>(a, b[, c], ck) for NAND AND OR XOR XNOR NOR ANDNY ANDYN ORNY ORYN MUX
 //
+// The programmable-bootstrap seam (BASELINE config 4; -uint5=true, the default), at params.SecurityUint5 after the
+// 128-bit part (a fresh evaluator.NewEvaluator(N): gates.globalEval was sized at package init and is not touched again):
+//
+//	small/
+//	  uint5_params.npy           int64 [9]: n, N, Nbit, L, Bgbit, basebit, t, decomposition offset, messageModulus (32)
+//	  uint5_lut_identity.npy, uint5_lut_mod16.npy, uint5_lut_ge16.npy
+//	                             uint32 [2][N]        lut.Generator.GenLookUpTableAssign (lut/generator.go:56-100) of x, x mod 16,
+//	                                                  [x >= 16]: Poly.A then Poly.B -- exact integers: the oracle's generator and
+//	                                                  go-tfhe_amd/lut.py must match them bit for bit
+//	big/uint5/  (70 MB + 1.69 GB of keys: not for the repository)
+//	  key_lv0.npy, key_lv1.npy, bsk_fourier.npy [n][2L][2][N], ksk.npy [N*t*base][n+1]
+//	  pbs_msgs.npy               int64 [P]            the encrypted messages (tlwe/programmable_encrypt.go:12-26, modulus 32)
+//	  pbs_lut.npy                int64 [P]            which table each item goes through: 0 identity, 1 mod 16, 2 >= 16
+//	  pbs_in.npy                 uint32 [P][n+1]      EncryptLWEMessage(m, 32, alpha, KeyLv0)
+//	  pbs_out.npy                uint32 [P][n+1]      Evaluator.BootstrapLUTAssign (evaluator/programmable_bootstrap.go:93-115)
+//	  pbs_dec.npy                int64 [P]            DecryptLWEMessage(32, KeyLv0) of pbs_out
+//	This parameter shape is in the fp64 TOLERANCE regime (values reach 2^58: two correct FFT pipelines differ in low bits and
+//	digits flip downstream, SURVEY.md 8c(4)), so pbs_out is compared by decryption and phase distance, not word for word.
+//
 // Key generation in the reference draws from auto-seeded generators and fans out over goroutines, so the KEY is
 // not reproducible from a seed; that is why the key itself is part of the dump.  Given the key, every function on
 // the path is deterministic, which is all parity needs.
@@ -50,6 +69,7 @@ import (
 	"github.com/thedonutfactory/go-tfhe/evaluator"
 	"github.com/thedonutfactory/go-tfhe/gates"
 	"github.com/thedonutfactory/go-tfhe/key"
+	"github.com/thedonutfactory/go-tfhe/lut"
 	"github.com/thedonutfactory/go-tfhe/params"
 	"github.com/thedonutfactory/go-tfhe/poly"
 	"github.com/thedonutfactory/go-tfhe/tlwe"
@@ -136,11 +156,15 @@ func flattenLWEs(cts []*tlwe.TLWELv0) []params.Torus {
 	return out
 }
 
+type gate2 func(a, b *gates.Ciphertext, ck *cloudkey.CloudKey) *gates.Ciphertext
+
 func main() {
 	outDir := flag.String("out", "go_golden_out", "output directory")
 	batch := flag.Int("batch", 8, "ciphertexts per full-key vector")
 	steps := flag.Int("steps", 4, "CMUX steps in the small chain fixture")
 	seed := flag.Int64("seed", 0x7F4E0020, "seed of the input generator (the key is dumped, not seeded)")
+	uint5 := flag.Bool("uint5", true, "also dump the programmable-bootstrap seam at params.SecurityUint5 (1.8 GB of keys under big/uint5)")
+	pbs := flag.Int("pbs", 8, "programmable bootstraps in the Uint5 vector")
 	flag.Parse()
 	small, big := filepath.Join(*outDir, "small"), filepath.Join(*outDir, "big")
 	must(os.MkdirAll(small, 0o755))
@@ -240,7 +264,6 @@ func main() {
 	writeNpy(filepath.Join(big, "gate_a.npy"), "<u4", []int{B, n + 1}, u32Bytes(flattenLWEs(ga)))
 	writeNpy(filepath.Join(big, "gate_b.npy"), "<u4", []int{B, n + 1}, u32Bytes(flattenLWEs(gb)))
 	writeNpy(filepath.Join(big, "gate_c.npy"), "<u4", []int{B, n + 1}, u32Bytes(flattenLWEs(gc)))
-	type gate2 func(a, b *gates.Ciphertext, ck *cloudkey.CloudKey) *gates.Ciphertext
 	two := map[string]gate2{"NAND": gates.NAND, "AND": gates.AND, "OR": gates.OR, "XOR": gates.XOR, "XNOR": gates.XNOR,
 		"NOR": gates.NOR, "ANDNY": gates.ANDNY, "ANDYN": gates.ANDYN, "ORNY": gates.ORNY, "ORYN": gates.ORYN}
 	for name, fn := range two {
@@ -259,5 +282,75 @@ func main() {
 		copy(mux[b].P, r.P)
 	}
 	writeNpy(filepath.Join(big, "gate_MUX.npy"), "<u4", []int{B, n + 1}, u32Bytes(flattenLWEs(mux)))
+	if *uint5 {
+		dumpUint5(small, filepath.Join(big, "uint5"), *pbs, rng)
+	}
 	fmt.Println("wrote", small, "and", big)
+}
+
+// dumpUint5 is params/uint_params_test.go:46-71 with everything written out: the three lookup tables of the reference's
+// nibble adder (examples/add_two_numbers/main.go:59-72) and P programmable bootstraps through them.
+func dumpUint5(small, bigDir string, P int, rng *rand.Rand) {
+	must(os.MkdirAll(bigDir, 0o755))
+	params.CurrentSecurityLevel = params.SecurityUint5
+	const messageModulus = 32
+	lv0, g1 := params.GetTLWELv0(), params.GetTRGSWLv1()
+	n, N, L := lv0.N, g1.N, g1.L
+	base := 1 << g1.BASEBIT
+
+	sk := key.NewSecretKey()
+	ck := cloudkey.NewCloudKey(sk)
+	eval := evaluator.NewEvaluator(N)
+	writeNpy(filepath.Join(small, "uint5_params.npy"), "<i8", []int{9},
+		i64Bytes([]int64{int64(n), int64(N), int64(g1.NBIT), int64(L), int64(g1.BGBIT), int64(g1.BASEBIT), int64(g1.IKS_T), int64(ck.DecompositionOffset), messageModulus}))
+
+	gen := lut.NewGenerator(messageModulus)
+	funcs := []func(int) int{
+		func(x int) int { return x },
+		func(x int) int { return x % 16 },
+		func(x int) int {
+			if x >= 16 {
+				return 1
+			}
+			return 0
+		},
+	}
+	names := []string{"identity", "mod16", "ge16"}
+	tables := make([]*lut.LookUpTable, len(funcs))
+	for i, f := range funcs {
+		tables[i] = lut.NewLookUpTable()
+		gen.GenLookUpTableAssign(f, tables[i])
+		writeNpy(filepath.Join(small, "uint5_lut_"+names[i]+".npy"), "<u4", []int{2, N}, u32Bytes(flattenTRLWE(tables[i].Poly)))
+	}
+
+	writeNpy(filepath.Join(bigDir, "key_lv0.npy"), "<u4", []int{n}, u32Bytes(sk.KeyLv0))
+	writeNpy(filepath.Join(bigDir, "key_lv1.npy"), "<u4", []int{N}, u32Bytes(sk.KeyLv1))
+	var bsk []float64
+	for i := 0; i < n; i++ {
+		bsk = append(bsk, flattenTRGSW(ck.BootstrappingKey[i])...)
+	}
+	writeNpy(filepath.Join(bigDir, "bsk_fourier.npy"), "<f8", []int{n, 2 * L, 2, N}, f64Bytes(bsk))
+	writeNpy(filepath.Join(bigDir, "ksk.npy"), "<u4", []int{N * g1.IKS_T * base, n + 1}, u32Bytes(flattenLWEs(ck.KeySwitchingKey)))
+
+	msgs := make([]int64, P)
+	which := make([]int64, P)
+	dec := make([]int64, P)
+	ins := make([]*tlwe.TLWELv0, P)
+	outs := make([]*tlwe.TLWELv0, P)
+	for i := 0; i < P; i++ {
+		m := rng.Intn(messageModulus)
+		w := i % len(tables)
+		msgs[i] = int64(m)
+		which[i] = int64(w)
+		ins[i] = tlwe.NewTLWELv0()
+		ins[i].EncryptLWEMessage(m, messageModulus, lv0.ALPHA, sk.KeyLv0)
+		outs[i] = tlwe.NewTLWELv0()
+		eval.BootstrapLUTAssign(ins[i], tables[w], ck.BootstrappingKey, ck.KeySwitchingKey, ck.DecompositionOffset, outs[i])
+		dec[i] = int64(outs[i].DecryptLWEMessage(messageModulus, sk.KeyLv0))
+	}
+	writeNpy(filepath.Join(bigDir, "pbs_msgs.npy"), "<i8", []int{P}, i64Bytes(msgs))
+	writeNpy(filepath.Join(bigDir, "pbs_lut.npy"), "<i8", []int{P}, i64Bytes(which))
+	writeNpy(filepath.Join(bigDir, "pbs_in.npy"), "<u4", []int{P, n + 1}, u32Bytes(flattenLWEs(ins)))
+	writeNpy(filepath.Join(bigDir, "pbs_out.npy"), "<u4", []int{P, n + 1}, u32Bytes(flattenLWEs(outs)))
+	writeNpy(filepath.Join(bigDir, "pbs_dec.npy"), "<i8", []int{P}, i64Bytes(dec))
 }

@@ -34,4 +34,22 @@ np.save(os.path.join(big, "gate_bits.npy"), gb)
 for nm, v in (("a", ga), ("b", gbb), ("c", gc)): np.save(os.path.join(big, f"gate_{nm}.npy"), v)
 for op in ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX"]:
     np.save(os.path.join(big, f"gate_{op}.npy"), o.gate_batch(p, bsk, ksk, op, ga, gbb, gc if op == "MUX" else None)[0])
+# ---- the programmable-bootstrap seam (Uint5); the key is generated at a REDUCED n (a full Uint5 key-switching key is 1.7 GB):
+# tests/test_go_golden.py reads n from uint5_params.npy
+p5 = o.params("uint5").small(int(os.environ.get("SELFCHECK_UINT5_N", "24"))); m = 32
+big5 = os.path.join(big, "uint5"); os.makedirs(big5, exist_ok=True)
+rng5 = o.rng(0x7F4E0021); t0, t1 = o.keygen_secret(p5, rng5)
+_, bsk5 = o.keygen_bsk(p5, rng5, t0, t1, torus=False, fourier=True); ksk5 = o.keygen_ksk(p5, rng5, t0, t1)
+np.save(os.path.join(small, "uint5_params.npy"), np.array([p5.n, p5.N, p5.Nbit, p5.L, p5.Bgbit, p5.basebit, p5.t, o.offset(p5), m], np.int64))
+funcs = [("identity", lambda x: x), ("mod16", lambda x: x % 16), ("ge16", lambda x: int(x >= 16))]
+tabs = [o.lut_generate(p5, [f(x) for x in range(m)]) for _, f in funcs]
+for (nm, _), t in zip(funcs, tabs): np.save(os.path.join(small, f"uint5_lut_{nm}.npy"), t)
+np.save(os.path.join(big5, "key_lv0.npy"), t0); np.save(os.path.join(big5, "key_lv1.npy"), t1)
+np.save(os.path.join(big5, "bsk_fourier.npy"), bsk5); np.save(os.path.join(big5, "ksk.npy"), ksk5)
+P = 6; msgs = rs.randint(0, m, P).astype(np.int64); which = (np.arange(P) % 3).astype(np.int64)
+ins = np.stack([o.encrypt_message(p5, rng5, int(x), m, t0) for x in msgs])
+outs = np.stack([o.bootstrap(p5, bsk5, ksk5, ins[i], tabs[which[i]]) for i in range(P)])
+np.save(os.path.join(big5, "pbs_msgs.npy"), msgs); np.save(os.path.join(big5, "pbs_lut.npy"), which)
+np.save(os.path.join(big5, "pbs_in.npy"), ins); np.save(os.path.join(big5, "pbs_out.npy"), outs)
+np.save(os.path.join(big5, "pbs_dec.npy"), np.array([o.decrypt_message(p5, m, t0, r) for r in outs], np.int64))
 print("schema fixtures (ORACLE-made, pin nothing) in", out)
