@@ -528,15 +528,12 @@ struct KeySwitchArgs {
     uint32_t *out;           // [B][n+1]
     int n, N, t, basebit, n1p;
     const int *count;        // optional device-side item count (list launches): only min(B, *count) items exist
-    int count_base;          // ... of which this launch's items start at count_base (chunked launches)
-    uint32_t *xsum;          // k_keyswitch_wide: [8][xstride] partial sums, one copy per XCD (nullptr: atomics straight into out)
-    size_t xstride;
 };
 __device__ __forceinline__ int ks_items(const KeySwitchArgs &A, int B)
 {
     if (!A.count) return B;
-    const int c = *A.count - A.count_base;
-    return c < B ? (c < 0 ? 0 : c) : B;
+    const int c = *A.count;
+    return c < B ? c : B;
 }
 
 // `parts` > 1 (few ciphertexts, many idle CUs): workgroup (item, part) sums the rows of digit range `part` of the item and adds its
@@ -614,20 +611,6 @@ __global__ __launch_bounds__(256) void k_extract_keyswitch(KeySwitchArgs A, int 
 // ranges are combined with 32-bit atomic adds into `out`, which k_ks_init has set to (0, ..., 0, b)
 // (keyswitch.go:18-21).
 // ------------------------------------------------------------------------------------
-// The partial sums of k_keyswitch_wide, one copy per XCD, folded into the output: out = (0, ..., 0, b) + sum over the 8 copies.
-static __global__ void k_ks_xsum_reduce(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, const uint32_t *__restrict__ xsum,
-                                        size_t xstride, int n, int N, int B, const int *__restrict__ count, int count_base)
-{
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (count) { const int c = *count - count_base; if (c < B) B = c < 0 ? 0 : c; }
-    if (idx >= (size_t)B * (n + 1)) return;
-    const int b = (int)(idx / (n + 1)), x = (int)(idx % (n + 1));
-    uint32_t v = x == n ? trlwe[(size_t)b * 2 * N + N] : 0u;
-#pragma unroll
-    for (int k = 0; k < 8; k++) v += xsum[(size_t)k * xstride + idx];
-    out[idx] = v;
-}
-
 static __global__ void k_ks_init(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int n, int N, int B,
                                  const int *__restrict__ count)
 {
@@ -838,24 +821,12 @@ __global__ __launch_bounds__(256) void k_keyswitch_wide(KeySwitchArgs A, int B, 
             }
         }
     }
-    // Partial sums of the coefficient ranges meet in 32-bit atomics (exact: the sum is commutative mod 2^32).  Straight into
-    // `out` the ~20 workgroups that share an output tile sit on different XCDs, and every update moves the tile's lines from one
-    // XCD's L2 to another's through memory: 197.6 MB written per launch for 2.2 MB of results at Uint5 x 512 (rocprofv3 WRITE_SIZE,
-    // round 4).  With one partial copy PER XCD -- the workgroup adds into the copy of the XCD it is actually running on
-    // (XCC_ID; where it runs is a matter of speed only, every atomic is coherent) -- a line is only ever touched through one L2,
-    // stays there, and leaves once; k_ks_xsum_reduce folds the 8 copies into the output.
-    uint32_t *obase = A.out;
-    if (A.xsum) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        obase = A.xsum + (size_t)(xcc & 7u) * A.xstride;
-    }
     const int col = c0 + lane;
     if (col <= A.n) {
 #pragma unroll
         for (int b = 0; b < CT; b++) {
             if (b0 + b >= B) break;
-            if (acc[b]) atomicAdd(obase + (size_t)(b0 + b) * (A.n + 1) + col, acc[b]);
+            if (acc[b]) atomicAdd(A.out + (size_t)(b0 + b) * (A.n + 1) + col, acc[b]);
         }
     }
 }

@@ -124,8 +124,6 @@ struct tfhe_ctx {
     DevBuf status;              // one int: kStatus* bits set by kernels (bad op codes on the _dev path)
     DevBuf kskB;                // byte-column copy of the key-switching key for the MFMA form (keyswitch_mfma.hpp; base-4 sets)
     DevBuf s_onehot;            // its per-launch one-hot digit matrix
-    DevBuf s_ksx;               // k_keyswitch_wide: partial sums, one copy per XCD, of one chunk of ciphertexts (launch_keyswitch)
-    int ks_xcd_sum = 1;         // TFHE_OPT_KS_XCD_SUM: 1 = per-XCD partial sums + reduce, 0 = atomics straight into the output
     int ks_mfma_min = 0;        // batches of at least this many ciphertexts use it
     int ks_wide_ct = 0;         // k_keyswitch_wide: ciphertexts per wave, 0 = by batch size (TFHE_OPT_KS_WIDE_CT)
     DevBuf bskq, twq;           // four-wave layout of the key + its twiddles (N = 1024 shapes, kernels_quad.hpp)
@@ -355,9 +353,6 @@ constexpr int kKsMfmaMinDefault = 24;       // from 24 ciphertexts on; below, th
                                             // ciphertext is quicker (128-bit set: 0.026-0.030 vs 0.038-0.040 ms at 1...16, 0.042 vs 0.038 at 31;
                                             // at 1,024: 0.135 vs 0.51 ms for the tiled vector kernel) -- profiles/r04_t_small_launches_uint.txt
 constexpr int kKsMfmaChunk = 1024;           // ciphertexts per one-hot matrix (38 MB at the 128-bit set)
-constexpr int kKsWideChunk = 2048;           // ciphertexts per launch of the wide key switch with per-XCD partial sums (8 copies of
-                                             // chunk x (n + 1) words: 70 MB at the Uint5 set)
-bool ks_wide_shape(const tfhe_params &P) { return P.basebit >= 4 && P.basebit <= 7; }
 int ks_mfma_pieces(const tfhe_params &P) { return P.t * P.N / (16 >> P.basebit); }      // 16-K pieces: K = N t base
 bool ks_mfma_shape(const tfhe_params &P)
 {
@@ -440,12 +435,6 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         int rc = grow(c, c->s_onehot, (size_t)ks_mfma_pieces(c->P) * MpadMax * sizeof(uint4), st, "one-hot digit");
         if (rc) return rc;
     }
-    const bool wide = !mfma && !(c->P.basebit == 2 && B >= 32 && c->P.N % 16 == 0) && ks_wide_shape(c->P) && B >= 64;
-    if (wide && c->ks_xcd_sum) {    // the per-XCD partial sums of one chunk (a no-op after reserve_scratch / the first call)
-        const int Bc = B < kKsWideChunk ? B : kKsWideChunk;
-        int rc = grow(c, c->s_ksx, (size_t)8 * Bc * (c->P.n + 1) * sizeof(uint32_t), st, "key-switch partial-sum");
-        if (rc) return rc;
-    }
     hipEvent_t stop;
     int trc = timing_begin(c, 1, st, &stop);
     if (trc) return trc;
@@ -496,69 +485,42 @@ int launch_keyswitch(tfhe_ctx *c, const uint32_t *d_trlwe, uint32_t *d_out, int 
         return timing_end(c, 1, st, stop);
     }
     // larger bases (Uint sets), batches that fill at least one wave of ciphertexts: column-sliced tiles
-    if (wide) {
+    if (c->P.basebit >= 4 && c->P.basebit <= 7 && B >= 64) {
         // 256 ciphertexts per workgroup (64 per wave).  The form with 128 per wave (a key row crosses L2 once per 512 ciphertexts)
         // needs 296 registers, i.e. one wave per SIMD: 0.92 vs 0.57 ms at Uint5 x 512 (profiles/r04_e_keyswitch_hbm.txt); it stays
         // selectable for measurements (TFHE_OPT_KS_WIDE_CT = 128).
         const bool big = c->ks_wide_ct == 128 && c->P.basebit <= 6;      // measured slower (one wave per SIMD): only on request
         const int per_wg = big ? 512 : 256;
-        const int col_blocks = (c->P.n + 1 + 63) / 64;
+        const int ct_tiles = (B + per_wg - 1) / per_wg, col_blocks = (c->P.n + 1 + 63) / 64;
         // coefficient ranges: as many as fill k whole rounds of the resident workgroups (three per CU by registers, two at
         // base 128 by LDS and with 128 ciphertexts per wave by registers) -- the kernel's time goes with rounds x coefficients
         // per workgroup, so a grid that ends in a part-filled round wastes the difference (Uint5 x 512: 1,088 workgroups on 768
         // slots 0.60 ms, 3,060 on 4 x 768 0.50 ms; profiles/r03_k_keyswitch_rounds.txt).  k = 1...8 with at least 20
         // coefficients per workgroup: the best fill, the larger k on a tie (shorter workgroups even out the tail).
-        const int slots = (big ? 1 : c->P.basebit >= 7 ? 2 : 3) * c->num_cus;
-        auto plan = [&](int Bx, int &ct_tiles_o, int &ranges_o) {
-            const int ct_tiles = (Bx + per_wg - 1) / per_wg, units = ct_tiles * col_blocks;
-            int ranges = 1;
-            double best_fill = 0.0;
-            for (int k = 1; k <= 8; k++) {
-                int r = (int)((long long)k * slots / units);
-                if (r > c->P.N / 20) r = c->P.N / 20;
-                if (r < 1) r = 1;
-                const long long wgs = (long long)units * r, rounds = (wgs + slots - 1) / slots;
-                const double fill = (double)wgs / (double)(rounds * slots);
-                if (fill >= best_fill - 0.005) { if (fill > best_fill) best_fill = fill; ranges = r; }
-            }
-            ct_tiles_o = ct_tiles; ranges_o = ranges;
-        };
-        auto launch = [&](const KeySwitchArgs &ka, int Bx) {
-            int ct_tiles, ranges;
-            plan(Bx, ct_tiles, ranges);
-            const dim3 g((unsigned)((col_blocks * ranges + 7) / 8 * 8 * ct_tiles));                // XCD decode: see the kernel
-#define KSW(BBv)                                                                                                            \
-            if (big) hipLaunchKernelGGL((k_keyswitch_wide<BBv, 128>), g, dim3(256), 0, st, ka, Bx, ranges, ct_tiles, col_blocks);     \
-            else hipLaunchKernelGGL((k_keyswitch_wide<BBv, 64>), g, dim3(256), 0, st, ka, Bx, ranges, ct_tiles, col_blocks)
-            switch (c->P.basebit) {
-            case 4: KSW(4); break;
-            case 5: KSW(5); break;
-            case 6: KSW(6); break;
-            default: hipLaunchKernelGGL((k_keyswitch_wide<7, 64>), g, dim3(256), 0, st, ka, Bx, ranges, ct_tiles, col_blocks); break;
-            }
-#undef KSW
-        };
-        const size_t n1 = (size_t)c->P.n + 1;
-        if (c->ks_xcd_sum) {
-            // partial sums per XCD (see the kernel's tail), in chunks of kKsWideChunk ciphertexts so that the eight copies have a fixed size
-            const int Bc0 = B < kKsWideChunk ? B : kKsWideChunk;
-            const size_t xstride = (size_t)Bc0 * n1;
-            for (int base = 0; base < B; base += kKsWideChunk) {
-                const int Bx = B - base < kKsWideChunk ? B - base : kKsWideChunk;
-                KeySwitchArgs ka = a;
-                ka.trlwe = d_trlwe + (size_t)base * 2 * c->P.N; ka.out = d_out + (size_t)base * n1;
-                ka.count_base = base; ka.xsum = c->s_ksx.as<uint32_t>(); ka.xstride = xstride;
-                HIP_TRY(hipMemsetAsync(c->s_ksx.p, 0, 8 * xstride * sizeof(uint32_t), st));
-                launch(ka, Bx);
-                const size_t tot = (size_t)Bx * n1;
-                hipLaunchKernelGGL(k_ks_xsum_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, ka.trlwe, ka.out, ka.xsum, xstride,
-                                   c->P.n, c->P.N, Bx, d_count, base);
-            }
-        } else {
-            const size_t tot = (size_t)B * n1;
-            hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
-            launch(a, B);
+        const int slots = (big ? 1 : c->P.basebit >= 7 ? 2 : 3) * c->num_cus, units = ct_tiles * col_blocks;
+        int ranges = 1;
+        double best_fill = 0.0;
+        for (int k = 1; k <= 8; k++) {
+            int r = (int)((long long)k * slots / units);
+            if (r > c->P.N / 20) r = c->P.N / 20;
+            if (r < 1) r = 1;
+            const long long wgs = (long long)units * r, rounds = (wgs + slots - 1) / slots;
+            const double fill = (double)wgs / (double)(rounds * slots);
+            if (fill >= best_fill - 0.005) { if (fill > best_fill) best_fill = fill; ranges = r; }
         }
+        const size_t tot = (size_t)B * (c->P.n + 1);
+        hipLaunchKernelGGL(k_ks_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_trlwe, d_out, c->P.n, c->P.N, B, d_count);
+        const dim3 g((unsigned)((col_blocks * ranges + 7) / 8 * 8 * ct_tiles));                // XCD decode: see the kernel
+#define KSW(BBv)                                                                                                            \
+        if (big) hipLaunchKernelGGL((k_keyswitch_wide<BBv, 128>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks);     \
+        else hipLaunchKernelGGL((k_keyswitch_wide<BBv, 64>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks)
+        switch (c->P.basebit) {
+        case 4: KSW(4); break;
+        case 5: KSW(5); break;
+        case 6: KSW(6); break;
+        default: hipLaunchKernelGGL((k_keyswitch_wide<7, 64>), g, dim3(256), 0, st, a, B, ranges, ct_tiles, col_blocks); break;
+        }
+#undef KSW
         HIP_TRY(hipGetLastError());
         return timing_end(c, 1, st, stop);
     }
@@ -611,10 +573,6 @@ int reserve_scratch(tfhe_ctx *c, int items, bool mux, hipStream_t st)
     if (c->kskB.p) {            // one-hot digit matrix of the matrix-core key switch (one chunk; launch_keyswitch)
         const int Bc = S < kKsMfmaChunk ? S : kKsMfmaChunk, Mpad = (Bc + kKsGroup - 1) / kKsGroup * kKsGroup;
         if ((rc = grow(c, c->s_onehot, (size_t)ks_mfma_pieces(c->P) * Mpad * sizeof(uint4), st, "one-hot digit"))) return rc;
-    }
-    if (ks_wide_shape(c->P) && c->ks_xcd_sum && S >= 64) {
-        const int Bc = S < kKsWideChunk ? S : kKsWideChunk;
-        if ((rc = grow(c, c->s_ksx, (size_t)8 * Bc * (c->P.n + 1) * sizeof(uint32_t), st, "key-switch partial-sum"))) return rc;
     }
     if (mux) {
         const int nb = (S + kPlanBlock - 1) / kPlanBlock;
@@ -1225,7 +1183,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->need_sync_all) (void)hipDeviceSynchronize();
     c->dev_marks.clear();
     for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->status, &c->s_plan, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
-                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3, &c->kskB, &c->s_onehot, &c->s_ksx})
+                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3, &c->kskB, &c->s_onehot})
         b->release();
     for (auto &pair : c->ev)
         for (auto &e : pair) if (e) (void)hipEventDestroy(e);
@@ -1280,7 +1238,6 @@ int tfhe_ctx_set_option(tfhe_ctx *c, int option, int value)
         return TFHE_OK;
     case TFHE_OPT_FROZEN: c->frozen = value != 0; return TFHE_OK;
     case TFHE_OPT_COMBINE_MAX: c->combine_max = value < 0 ? launch_items(c) : value; return TFHE_OK;
-    case TFHE_OPT_KS_XCD_SUM: c->ks_xcd_sum = value != 0; return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT:
         if (value > 0 && value != 64 && value != 128) return fail(TFHE_E_INVALID, "TFHE_OPT_KS_WIDE_CT is 64, 128 or 0 / -1 (by batch size)");
         c->ks_wide_ct = value < 0 ? 0 : value;
@@ -1301,7 +1258,6 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_COMBINE_MAX: *value = c->combine_max.load(); return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT: *value = c->ks_wide_ct; return TFHE_OK;
     case TFHE_OPT_CLONE_PATH: *value = c->clone_path; return TFHE_OK;
-    case TFHE_OPT_KS_XCD_SUM: *value = c->ks_xcd_sum; return TFHE_OK;
     // the counters are 64-bit; the option interface is int: saturate instead of wrapping
     case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)std::min<long long>(c->comb_launches.load(), INT_MAX); return TFHE_OK;
     case TFHE_OPT_COMBINE_REQUESTS: *value = (int)std::min<long long>(c->comb_requests.load(), INT_MAX); return TFHE_OK;
@@ -1657,7 +1613,7 @@ int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out)
     std::lock_guard<std::recursive_mutex> lk(src->mu);            // no key load on the source while it is being read
     // the per-context limits travel with the key: a clone dispatches like its source
     dst->quad_limit = src->quad_limit; dst->oct_limit = src->oct_limit; dst->ks_mfma_min = src->ks_mfma_min;
-    dst->ks_wide_ct = src->ks_wide_ct; dst->combine_max = src->combine_max.load(); dst->ks_xcd_sum = src->ks_xcd_sum;
+    dst->ks_wide_ct = src->ks_wide_ct; dst->combine_max = src->combine_max.load();
     bool peers = false;
     void *bounce = nullptr;
     struct Bounce { void *&p; ~Bounce() { if (p) (void)hipHostFree(p); } } bounce_guard{bounce};

@@ -122,10 +122,6 @@ enum {
     TFHE_OPT_COMBINE_REQUESTS = 7,  /* ... and the tfhe_gate_batch calls they carried                                       */
     TFHE_OPT_KS_WIDE_CT = 8,   /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
                                   only: one wave per SIMD, slower)                                                         */
-    TFHE_OPT_KS_XCD_SUM = 10,  /* wide key switch (bases 16-128): 1 (default) = the partial sums of the coefficient ranges meet in
-                                  one copy per XCD (each line stays in one L2) and a second kernel folds the copies into the
-                                  output; 0 = 32-bit atomics straight into the output (round 4: the output's lines move between
-                                  the XCDs' L2s, 90 x the output in HBM writes).  Same words either way.                    */
     TFHE_OPT_CLONE_PATH = 9    /* read-only: how tfhe_ctx_clone_to brought this context's keys here: 0 = not a clone, 1 = same
                                   GPU (device-to-device copy), 2 = peer copy GPU to GPU (xGMI), 3 = staged through page-locked
                                   host memory (the devices are not peers)                                                  */

@@ -14,8 +14,6 @@ p = pkg.params.BY_NAME[pname]
 rs = np.random.RandomState(1)
 rnd = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
 ck = pkg.CloudKey(p, bsk_torus=rnd((p.n, 2 * p.L, 2, p.N)), ksk=rnd((p.ksk_rows, p.n + 1)))
-if os.environ.get("KS_XCD_SUM") is not None:            # round 5: wide key switch with / without the per-XCD partial sums
-    ck.ctx.set_option("ks_xcd_sum", int(os.environ["KS_XCD_SUM"]))
 a = torch.from_numpy(rnd((B, p.n + 1)).view(np.int32)).cuda()
 b = torch.from_numpy(rnd((B, p.n + 1)).view(np.int32)).cuda()
 lut = torch.from_numpy(rnd((2, p.N)).view(np.int32)).cuda()
