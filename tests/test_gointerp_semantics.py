@@ -1,0 +1,298 @@
+"""The Go-subset interpreter (tools/go_static/gointerp.py) is what executes the reference's sources for tests/golden/goref/: its own
+semantics are tested here on small Go programs whose results follow from the Go specification -- wrap-around of fixed-width integers,
+truncating division, conversions, shifts, slices sharing their backing array, append, copy, value semantics of structs and arrays,
+pointers, pointer-to-array views through unsafe.Pointer (the idiom of poly/fourier_transform.go), methods with value and pointer
+receivers, closures, multiple results, defer order, switch, range, complex128, math.Round.  No reference source is needed for these."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "go_static"))
+
+PRELUDE = """package t
+
+import (
+	"math"
+	"math/cmplx"
+	"unsafe"
+)
+
+type Torus uint32
+
+type Pair struct {
+	A []Torus
+	N int
+}
+
+type Box struct {
+	P   Pair
+	Arr [4]int
+}
+
+func (p Pair) Len() int { return len(p.A) }
+
+func (p *Pair) Grow() { p.N++ }
+
+func (p Pair) GrowCopy() { p.N++ }
+"""
+
+
+def run(body, fn="F", args=()):
+    import gointerp as gi
+    I = gi.Interp("/nonexistent")
+    I.load_source("t", {"t.go": PRELUDE + body})
+    return I.call_func("t", fn, *args)
+
+
+def test_fixed_width_arithmetic_wraps_and_int_does_not():
+    r = run("""
+func F() (Torus, Torus, Torus, int32, uint32, int) {
+	var a Torus = 0xFFFFFFFF
+	b := a + 2                      // wraps
+	c := Torus(0) - 1               // wraps
+	d := -a                         // two's complement
+	e := int32(a)                   // reinterpretation
+	f := uint32(int64(-5))          // conversion wraps
+	g := 1 << 40                    // int is 64 bits
+	return b, c, d, e, f, g
+}""")
+    assert [int(x) for x in r] == [1, 0xFFFFFFFF, 1, -1, 0xFFFFFFFB, 1 << 40]
+    assert isinstance(r[0], np.uint32) and isinstance(r[3], np.int32)
+
+
+def test_division_and_remainder_truncate_toward_zero():
+    assert run("func F() (int, int, int, int) { a := -7; b := 2; return a / b, a % b, 7 / -2, 7 % -2 }") == (-3, -1, -3, 1)
+    r = run("func F() (int32, int32) { var a int32 = -7; var b int32 = 2; return a / b, a % b }")
+    assert (int(r[0]), int(r[1])) == (-3, -1)
+
+
+def test_float_to_integer_conversion_truncates_and_mod_follows_the_dividend():
+    assert run("func F() (int64, int64, float64, float64) { return int64(-3.9), int64(3.9), math.Mod(-0.5, 1.0), math.Mod(2.75, 1.0) }") == (-3, 3, -0.5, 0.75)
+    r = run("func F() Torus { d := -0.125; return Torus(int64(math.Mod(d, 1.0) * float64(uint64(1)<<32))) }")     # utils.F64ToTorus's shape
+    assert int(r) == 0xE0000000
+
+
+def test_shifts_keep_the_left_operands_type():
+    r = run("""
+func F() (Torus, Torus, int, Torus) {
+	var a Torus = 0x80000001
+	n := 4
+	var m uint32 = 31
+	return a << n, a >> n, 1 << n, (a + (1 << (31 - n - 1))) >> m
+}""")
+    assert [int(x) for x in r] == [0x10, 0x08000000, 16, 1]
+    assert isinstance(r[0], np.uint32)
+
+
+def test_untyped_constants_take_the_type_of_their_context():
+    r = run("""
+const half = 1 << 5
+func F() (Torus, float64, Torus) {
+	var t Torus = 10
+	x := t - half                   // untyped constant becomes Torus: wraps
+	var f float64 = half            // ... or float64
+	y := ^Torus(0) - t
+	return x, f / 3, y
+}""")
+    assert int(r[0]) == (10 - 32) & 0xFFFFFFFF and r[1] == 32 / 3 and int(r[2]) == 0xFFFFFFFF - 10
+
+
+def test_slices_share_their_backing_array_and_append_respects_capacity():
+    r = run("""
+func F() ([]int, []int, []int, int, int) {
+	a := make([]int, 3, 8)
+	b := a[1:3]
+	b[0] = 7                        // visible through a
+	c := append(b, 9)               // fits the capacity: writes a's backing array
+	d := a[0:4]
+	e := append(a[:3:3], 5)         // full slice expression: capacity 3 -> reallocates
+	e[0] = 100                      // not visible through a
+	return a, d, c, len(e), cap(b)
+}""")
+    import gointerp as gi
+    as_list = lambda s: s.a[s.o:s.o + s.n]                                                    # noqa: E731
+    assert as_list(r[0]) == [0, 7, 0] and as_list(r[1]) == [0, 7, 0, 9] and as_list(r[2]) == [7, 0, 9] and r[3] == 4 and r[4] == 7
+    _ = gi
+
+
+def test_copy_and_range_and_nil_slices():
+    r = run("""
+func F() (int, int, int, []Torus) {
+	src := []Torus{1, 2, 3, 4}
+	dst := make([]Torus, 2)
+	n := copy(dst, src)
+	var none []Torus
+	sum := 0
+	for i, v := range src { sum += i * int(v) }
+	for range none { sum = -1 }
+	none = append(none, src[2:]...)
+	return n, sum, len(none), dst
+}""")
+    assert r[0] == 2 and r[1] == 0 * 1 + 1 * 2 + 2 * 3 + 3 * 4 and r[2] == 2 and [int(x) for x in r[3].a[:2]] == [1, 2]
+
+
+def test_structs_and_arrays_are_values_pointers_alias():
+    r = run("""
+func F() (int, int, int, int, int, int) {
+	p := Pair{A: make([]Torus, 2), N: 1}
+	q := p                          // copy: N independent, A shares its backing array
+	q.N = 5
+	q.A[0] = 9
+	r := &p
+	r.N = 7                         // through the pointer
+	var b Box
+	b.P = p                         // copy into a field
+	b.P.N = 11
+	arr := b.Arr
+	arr[0] = 3                      // arrays are values
+	return p.N, q.N, int(p.A[0]), b.P.N, b.Arr[0], arr[0]
+}""")
+    assert r == (7, 5, 9, 11, 0, 3)
+
+
+def test_value_and_pointer_receivers():
+    assert run("""
+func F() (int, int, int) {
+	p := Pair{A: make([]Torus, 3)}
+	p.Grow()                        // pointer receiver on an addressable value
+	p.GrowCopy()                    // value receiver: works on a copy
+	q := &p
+	q.Grow()
+	return p.N, p.Len(), q.Len()
+}""") == (2, 3, 3)
+
+
+def test_pointer_to_array_views_through_unsafe_pointer_write_through():
+    # the idiom of poly/fourier_transform.go:64-125,178-347
+    r = run("""
+func F() ([]float64, float64) {
+	c := make([]float64, 16)
+	for i := range c { c[i] = float64(i) }
+	u := (*[4]float64)(unsafe.Pointer(&c[4]))
+	v := (*[4]float64)(unsafe.Pointer(&c[8]))
+	u[0], v[0] = v[0], u[0]         // tuple assignment: both sides evaluated first
+	u[3] += 0.5
+	return c, v[3]
+}""")
+    assert r[0].a[4] == 8.0 and r[0].a[8] == 4.0 and r[0].a[7] == 7.5 and r[1] == 11.0
+
+
+def test_multiple_results_closures_and_defer_order():
+    assert run("""
+func split(x int) (int, int) { return x / 10, x % 10 }
+func F() (int, int, int, []int) {
+	a, b := split(47)
+	counter := 0
+	inc := func() int { counter++; return counter }
+	inc(); inc()
+	order := make([]int, 0, 3)
+	func() {
+		defer func() { order = append(order, 1) }()
+		defer func() { order = append(order, 2) }()
+		order = append(order, 0)
+	}()
+	return a, b, counter, order
+}""")[:3] == (4, 7, 2)
+    r = run("""
+func F() []int {
+	order := make([]int, 0, 3)
+	func() {
+		defer func() { order = append(order, 1) }()
+		defer func() { order = append(order, 2) }()
+		order = append(order, 0)
+	}()
+	return order
+}""")
+    assert r.a[:3] == [0, 2, 1]                                                               # LIFO
+
+
+def test_named_results_switch_and_loops():
+    assert run("""
+func classify(x int) (name string, ok bool) {
+	switch {
+	case x < 0:
+		name = "neg"
+	case x == 0:
+		name = "zero"
+		ok = true
+	default:
+		name = "pos"
+		ok = true
+	}
+	return
+}
+func pick(level int) int {
+	switch level {
+	case 80, 110:
+		return 1
+	case 128:
+		return 2
+	default:
+		return 3
+	}
+}
+func F() (string, bool, string, int, int, int) {
+	a, _ := classify(-1)
+	b, okb := classify(0)
+	total := 0
+	for m, t := 1, 8; m <= 8; m, t = m<<1, t>>1 {
+		if m == 4 { continue }
+		total += m * t
+	}
+	for i := 0; ; i++ { if i == 3 { break }; total++ }
+	return a, okb, b, pick(110), pick(128), total
+}""") == ("neg", True, "zero", 1, 2, 8 + 8 + 8 + 3)
+
+
+def test_complex128_and_math_round():
+    r = run("""
+func F() (float64, float64, complex128, float64, float64, float64, float64) {
+	w := cmplx.Exp(complex(0, math.Pi/2))
+	z := complex(1, 2) * complex(3, -1)
+	return real(w), imag(w), z, math.Round(2.5), math.Round(-2.5), math.Round(0.49999999999999994), math.Round(4503599627370497.0)
+}""")
+    assert abs(r[0]) < 1e-15 and r[1] == 1.0 and r[2] == complex(5, 5)
+    assert r[3:] == (3.0, -3.0, 0.0, 4503599627370497.0)                                     # halves away from zero; exact near 0.5 and above 2^52
+
+
+def test_maps_and_comma_ok_and_string_concat():
+    assert run("""
+func F() (int, bool, bool, string) {
+	m := map[string]int{"a": 1}
+	m["b"] = 2
+	v, ok := m["b"]
+	_, no := m["zz"]
+	delete(m, "a")
+	return v + len(m), ok, no, "x" + "y"
+}""") == (3, True, False, "xy")
+
+
+def test_out_of_range_index_panics_like_go():
+    import gointerp as gi
+    with pytest.raises(gi.GoPanic, match="index out of range"):
+        run("func F() int { a := make([]int, 2); return a[2] }")
+    with pytest.raises(gi.GoPanic, match="slice bounds"):
+        run("func F() []int { a := make([]int, 2, 4); return a[1:5] }")
+    with pytest.raises(gi.GoPanic, match="boom"):
+        run('func F() int { panic("boom") }')
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/poly"), reason="/root/reference is absent (GPU box)")
+def test_live_the_references_transform_under_the_interpreter_equals_the_oracle(oracle):
+    # the fixtures of tests/golden/goref/ are regenerable: here one forward transform and one decomposition are executed from the
+    # reference's source right now and compared with the oracle (bitwise) -- and with the committed fixture
+    import gointerp as gi
+    I = gi.Interp("/root/reference")
+    pe = I.call_func("poly", "NewEvaluator", 1024)
+    f = np.load(os.path.join(ROOT, "tests", "golden", "goref", "fft.npz"))
+    p = f["polys_1024"][0]
+    TORUS = I.named(I.load("params"), "Torus")
+    fp = I.call_method(pe, "ToFourierPoly", gi.GoStruct(I.named(I.load("poly"), "Poly"), {"Coeffs": gi.np_to_slice(p, TORUS, np.uint32)}))
+    got = gi.slice_to_np(fp.f["Coeffs"], np.float64)
+    assert np.array_equal(got, oracle.to_fourier(p)) and np.array_equal(got, f["spectra_1024"][0])
+    assert int(I.call_func("utils", "F64ToTorus", 0.125)) == 0x20000000 and int(I.call_func("utils", "F64ToTorus", -0.125)) == 0xE0000000
+    assert math.isclose(I.steps, I.steps)

@@ -260,13 +260,21 @@ class Parser:
                 if depth == 0:
                     break
         sig = self.signature(line)
-        body = None
+        body, lazy = None, None
         if self.at("{"):
             if bodies:
                 body = self.block()
             else:
+                lazy = (self, self.p)                  # parse_lazy_body() parses it on demand (tools/go_static/gointerp.py)
                 self.skip_block()
-        return Node("funcdecl", line, name=name, recv=recv, sig=sig, body=body)
+        return Node("funcdecl", line, name=name, recv=recv, sig=sig, body=body, lazy=lazy)
+
+    def parse_body_at(self, pos):
+        saved, self.p = self.p, pos
+        try:
+            return self.block()
+        finally:
+            self.p = saved
 
     def skip_block(self):
         depth = 0
@@ -437,13 +445,19 @@ class Parser:
             return Node("defer", line, call=self.expr())
         if self.accept("go"):
             return Node("go", line, call=self.expr())
-        if self.accept("continue") or self.accept("break"):
-            return Node("branch", line)
+        if self.at("continue") or self.at("break"):
+            what = self.t.text
+            self.p += 1
+            if self.t.kind == "ident":
+                self.err("labelled break / continue is outside the checked subset")
+            return Node("branch", line, what=what)
         if self.accept("if"):
             return self.if_stmt(line)
         if self.accept("for"):
             return self.for_stmt(line)
-        for kw in ("switch", "select", "goto", "fallthrough", "type"):
+        if self.accept("switch"):
+            return self.switch_stmt(line)
+        for kw in ("select", "goto", "fallthrough", "type"):
             if self.at(kw):
                 self.err(f"`{kw}` is outside the checked subset")
         return self.simple_stmt()
@@ -458,11 +472,48 @@ class Parser:
                 return Node("rangeassign", line, lhs=lhs, define=op == ":=", x=self.expr(nolit))
             return Node("assign", line, lhs=lhs, op=op, rhs=self.expr_list(nolit))
         if self.at("++") or self.at("--"):
+            op = self.t.text
             self.p += 1
-            return Node("incdec", line, x=lhs[0])
+            return Node("incdec", line, x=lhs[0], op=op)
         if len(lhs) != 1:
             self.err("expression list is not a statement")
         return Node("exprstmt", line, x=lhs[0])
+
+    def switch_stmt(self, line):
+        """switch [init;] [tag] { case a, b: ... default: ... }   (expression switches; used by the interpreter, not by the shim checker)"""
+        init = tag = None
+        if not self.at("{"):
+            first = None if self.at(";") else self.simple_stmt(nolit=True)
+            if self.accept(";"):
+                init = first
+                if not self.at("{"):
+                    t = self.simple_stmt(nolit=True)
+                    if t.kind != "exprstmt":
+                        self.err("switch tag")
+                    tag = t.x
+            else:
+                if first is None or first.kind != "exprstmt":
+                    self.err("switch tag")
+                tag = first.x
+        self.expect("{")
+        clauses = []
+        self.skip_semis()
+        while not self.at("}"):
+            cl = self.t.line
+            if self.accept("default"):
+                exprs = None
+            else:
+                self.expect("case")
+                exprs = self.expr_list()
+            self.expect(":")
+            body = []
+            self.skip_semis()
+            while not (self.at("case") or self.at("default") or self.at("}")):
+                body.append(self.stmt())
+                self.skip_semis()
+            clauses.append((exprs, Node("block", cl, stmts=body)))
+        self.expect("}")
+        return Node("switch", line, init=init, tag=tag, clauses=clauses)
 
     def if_stmt(self, line):
         init = None
@@ -563,7 +614,11 @@ class Parser:
             if self.at("."):
                 self.p += 1
                 if self.at("("):
-                    self.err("type assertions are outside the checked subset")
+                    self.p += 1
+                    t = self.type_()
+                    self.expect(")")
+                    x = Node("typeassert", line, x=x, type=t)
+                    continue
                 x = Node("selector", line, x=x, sel=self.ident())
             elif self.at("("):
                 self.p += 1
