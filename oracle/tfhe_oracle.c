@@ -1,10 +1,18 @@
 /*
  * tfhe_oracle.c -- CPU restatement of go-tfhe's gate-bootstrap hot path (plain C).
  *
- * TEST INFRASTRUCTURE ONLY (see tfhe_oracle.h).  "parity unpinned" at the
- * ciphertext-sample level: the Go reference cannot run in this image and holds no
- * golden vectors for this path; the restatement is pinned by the reference's own
- * decrypt-level tests / KATs and by the exact-integer product below.
+ * TEST INFRASTRUCTURE ONLY (see tfhe_oracle.h).  How it is pinned: the Go reference holds no
+ * golden vectors for this path and the image has no Go toolchain, so no Go BINARY has ever
+ * produced a vector for it ("parity unpinned" in that sense: tests/test_go_golden.py skips).
+ * Since round 5 the reference's own SOURCE TEXT is executed here instead -- by
+ * tools/go_static/gointerp.py, a Go-subset interpreter that knows nothing about TFHE -- and
+ * this restatement is held, bit for bit, to what the reference's functions computed
+ * (tests/golden/goref/, tests/test_goref_vectors.py: transforms incl. their fp64 spectra,
+ * decomposition, rotation, key ingest, external product, CMUX, blind rotation, key switch,
+ * whole bootstraps and every gate at the full 128-bit set, lookup tables, Uint5 programmable
+ * bootstraps, and the reference's own key generation / encryption / decryption at a reduced
+ * LWE dimension), next to the reference's decrypt-level tests / KATs and the exact-integer
+ * product below.
  *
  * Build with -ffp-contract=off: Go on amd64 never fuses a*b+c, and the reference's
  * complex arithmetic is written as separate multiplies and adds.

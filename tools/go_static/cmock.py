@@ -1,0 +1,199 @@
+"""A stand-in for cgo's pseudo-package "C" so that the Go shim (shim/go/**) can be EXECUTED by gointerp.py where there is neither a Go
+toolchain nor a GPU: every C.tfhe_* entry point the shim calls is implemented here on top of the CPU oracle (tests/oracle_lib.py), with
+the semantics include/tfhe_hip.h documents (0 / negative return codes, tfhe_last_error, caller-owned outputs written through the
+pointers the shim passes).  Test infrastructure: what it validates is the SHIM's own logic -- flattening []*tlwe.TLWELv0 into the ABI's
+[B][n+1] planes and back, op codes, the key registry, CloudKeySet's contiguous shards and goroutine fan-out -- by comparing what the
+shim returns with what the reference's own gates return (both under the interpreter).  It says nothing about the GPU library."""
+import os
+import re
+
+import numpy as np
+
+import gointerp as gi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OPNAMES = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX"]
+
+
+class MockC:
+    def __init__(self, interp, oracle, device_count=2):
+        self.I, self.o, self.ndev = interp, oracle, device_count
+        self.err = ""
+        self.ctxs = []
+        self.calls = []                      # (name, detail) log: the tests look at it (which device ran how many items)
+        pkg = gi.Pkg("C", "C")
+        pkg.initialised = True
+        interp.pkgs["C"] = pkg
+        T = gi.BASIC_RT
+        for n in ("int", "int32_t", "size_t", "uint64_t", "int64_t", "long"):
+            pkg.native[n] = T["int"]
+        pkg.native["uint32_t"], pkg.native["uint8_t"], pkg.native["double"], pkg.native["char"] = T["uint32"], T["uint8"], T["float64"], T["int8"]
+        self.PARAMS = gi.RT("struct", fields=[(f, T["int"]) for f in ("n", "N", "Nbit", "L", "Bgbit", "basebit", "t")])
+        self.PARAMS._stub = "tfhe_params"
+        self.CTX = gi.RT("struct", fields=[("id", T["int"])])
+        self.CTX._stub = "tfhe_ctx"
+        pkg.native["tfhe_params"], pkg.native["tfhe_ctx"] = self.PARAMS, self.CTX
+        hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read()
+        hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+        for m in re.finditer(r"enum\s*\{(.*?)\}", hdr, flags=re.S):
+            nxt = 0
+            for em in re.finditer(r"(\w+)\s*(?:=\s*(-?\d+))?\s*(?:,|$)", m.group(1).strip()):
+                nxt = int(em.group(2)) if em.group(2) is not None else nxt
+                pkg.native[em.group(1)] = nxt
+                nxt += 1
+        for m in re.finditer(r"#define\s+(TFHE_\w+)\s+(-?\d+)", hdr):
+            pkg.native[m.group(1)] = int(m.group(2))
+        for name in [n for n in dir(self) if n.startswith("tfhe_")]:
+            pkg.native[name] = gi.Builtin(self._wrap(getattr(self, name), name), name)
+        pkg.native["GoString"] = gi.Builtin(lambda a: a[0], "GoString")
+
+    def _wrap(self, fn, name):
+        def call(a):
+            try:
+                return fn(*a)
+            except MockError as e:
+                self.err = str(e)
+                return e.code
+        return call
+
+    # ---- helpers
+    def ctx(self, h):
+        if h is None:
+            raise MockError(-1, "null context")
+        c = self.ctxs[int(h.v.f["id"])]
+        if c is None:
+            raise MockError(-1, "context already destroyed")
+        return c
+
+    @staticmethod
+    def read(ptr, count, dtype):
+        if ptr is None:
+            return None
+        if ptr.i + count > len(ptr.a):
+            raise MockError(-1, f"the shim handed C {len(ptr.a) - ptr.i} elements where the ABI reads {count}")
+        return np.array(ptr.a[ptr.i:ptr.i + count], dtype=dtype)
+
+    @staticmethod
+    def write(ptr, arr):
+        flat = np.ascontiguousarray(arr, np.uint32).reshape(-1)
+        if ptr.i + flat.size > len(ptr.a):
+            raise MockError(-1, "output buffer shorter than the ABI writes")
+        ptr.a[ptr.i:ptr.i + flat.size] = [np.uint32(x) for x in flat.tolist()]
+
+    def oparams(self, f):
+        n, N, L, Bg, bb, t = (int(f[k]) for k in ("n", "N", "L", "Bgbit", "basebit", "t"))
+        for name in ("80", "110", "128", "uint5", "uint1", "uint3", "uint4", "uint2"):
+            p = self.o.params(name)
+            if (p.N, p.L, p.Bgbit, p.basebit, p.t) == (N, L, Bg, bb, t):
+                return p.small(n)
+        raise MockError(-1, f"unsupported parameter shape N={N} L={L} Bgbit={Bg}")
+
+    # ---- the entry points the shim uses (include/tfhe_hip.h)
+    def tfhe_last_error(self):
+        return self.err
+
+    def tfhe_device_count(self, out):
+        gi.ptr_store(out, self.ndev)
+        return 0
+
+    def tfhe_ctx_create(self, pptr, device, out):
+        p = self.oparams(gi.ptr_load(pptr).f)
+        if not 0 <= int(device) < self.ndev:
+            raise MockError(-1, f"device {device} not present ({self.ndev} visible)")
+        self.ctxs.append({"p": p, "device": int(device), "bsk": None, "ksk": None, "clone_path": 0})
+        gi.ptr_store(out, gi.GoPtr(gi.GoStruct(self.CTX, {"id": len(self.ctxs) - 1})))
+        self.calls.append(("ctx_create", int(device)))
+        return 0
+
+    def tfhe_ctx_destroy(self, h):
+        if h is not None:
+            self.ctx(h)
+            self.ctxs[int(h.v.f["id"])] = None
+        return 0
+
+    def tfhe_ctx_clone_to(self, h, device, out):
+        src = self.ctx(h)
+        if not 0 <= int(device) < self.ndev:
+            raise MockError(-1, f"device {device} not present ({self.ndev} visible)")
+        self.ctxs.append({"p": src["p"], "device": int(device), "bsk": src["bsk"], "ksk": src["ksk"], "clone_path": 1 if int(device) == src["device"] else 2})
+        gi.ptr_store(out, gi.GoPtr(gi.GoStruct(self.CTX, {"id": len(self.ctxs) - 1})))
+        self.calls.append(("clone_to", int(device)))
+        return 0
+
+    def tfhe_ctx_get_option(self, h, opt, out):
+        c = self.ctx(h)
+        if int(opt) != self.I.pkgs["C"].native["TFHE_OPT_CLONE_PATH"]:
+            raise MockError(-1, f"option {opt} is not mocked")
+        gi.ptr_store(out, c["clone_path"])
+        return 0
+
+    def tfhe_load_bsk_fourier(self, h, ptr):
+        c = self.ctx(h)
+        p = c["p"]
+        c["bsk"] = self.read(ptr, p.n * 2 * p.L * 2 * p.N, np.float64).reshape(p.n, 2 * p.L, 2, p.N)
+        self.calls.append(("load_bsk", c["device"]))
+        return 0
+
+    def tfhe_load_ksk(self, h, ptr):
+        c = self.ctx(h)
+        p = c["p"]
+        c["ksk"] = self.read(ptr, p.ksk_rows * (p.n + 1), np.uint32).reshape(p.ksk_rows, p.n + 1)
+        self.calls.append(("load_ksk", c["device"]))
+        return 0
+
+    def _keys(self, c, need_ksk=True):
+        if c["bsk"] is None or (need_ksk and c["ksk"] is None):
+            raise MockError(-2, "cloud key not loaded")
+        return c["p"], c["bsk"], c["ksk"]
+
+    def tfhe_gate_batch(self, h, ops, op_uniform, a, b, cc, out, B):
+        c = self.ctx(h)
+        p, bsk, ksk = self._keys(c)
+        B, n1 = int(B), p.n + 1
+        A, Bb = self.read(a, B * n1, np.uint32).reshape(B, n1), self.read(b, B * n1, np.uint32).reshape(B, n1)
+        Cc = self.read(cc, B * n1, np.uint32).reshape(B, n1) if cc is not None else None
+        if ops is not None:
+            codes = self.read(ops, B, np.uint8)
+        else:
+            if not 0 <= int(op_uniform) <= 10:
+                raise MockError(-1, f"bad op code {op_uniform}")
+            codes = np.full(B, int(op_uniform), np.uint8)
+        if (codes == 10).any() and Cc is None:
+            raise MockError(-1, "MUX needs the third operand")
+        res, _ = self.o.gate_batch(p, bsk, ksk, codes, A, Bb, Cc)
+        self.write(out, res)
+        self.calls.append(("gate_batch", c["device"], B))
+        return 0
+
+    def tfhe_bootstrap_batch(self, h, inp, tv, per_item, out, B):
+        c = self.ctx(h)
+        p, bsk, ksk = self._keys(c)
+        B, n1 = int(B), p.n + 1
+        X = self.read(inp, B * n1, np.uint32).reshape(B, n1)
+        if tv is None:
+            T = self.o.gate_testvec(p)
+        elif int(per_item):
+            T = self.read(tv, B * 2 * p.N, np.uint32).reshape(B, 2, p.N)
+        else:
+            T = self.read(tv, 2 * p.N, np.uint32).reshape(2, p.N)
+        res, _ = self.o.bootstrap_batch(p, bsk, ksk, X, T)
+        self.write(out, res)
+        self.calls.append(("bootstrap_batch", c["device"], B))
+        return 0
+
+    def tfhe_blind_rotate_batch(self, h, inp, tv, per_item, out, B, nsteps):
+        c = self.ctx(h)
+        p, bsk, _ = self._keys(c, need_ksk=False)
+        B, n1 = int(B), p.n + 1
+        X = self.read(inp, B * n1, np.uint32).reshape(B, n1)
+        T = self.o.gate_testvec(p) if tv is None else self.read(tv, 2 * p.N, np.uint32).reshape(2, p.N)
+        res = np.stack([self.o.blind_rotate(p, bsk, X[i], T, int(nsteps)) for i in range(B)])
+        self.write(out, res)
+        self.calls.append(("blind_rotate_batch", c["device"], B))
+        return 0
+
+
+class MockError(Exception):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code

@@ -55,7 +55,7 @@ class Unsupported(Exception):
 
 class RT:
     """A resolved Go type."""
-    __slots__ = ("kind", "name", "elem", "key", "n", "fields", "under", "pkg", "_zero")
+    __slots__ = ("kind", "name", "elem", "key", "n", "fields", "under", "pkg", "_zero", "_stub")
 
     def __init__(self, kind, name=None, elem=None, key=None, n=0, fields=None, under=None, pkg=None):
         self.kind, self.name, self.elem, self.key, self.n, self.fields, self.under, self.pkg = kind, name, elem, key, n, fields, under, pkg
@@ -110,6 +110,14 @@ class VarPtr:
 
     def __init__(self, env, name):
         self.env, self.name = env, name
+
+
+class FieldPtr:
+    """&x.f of a struct field holding a non-struct value (e.g. &k.ctx handed to C, &s.next handed to atomic.AddUint32)."""
+    __slots__ = ("s", "name")
+
+    def __init__(self, s, name):
+        self.s, self.name = s, name
 
 
 class GoSlice:
@@ -269,7 +277,19 @@ class Interp:
             return self.pkgs[path]
         if path.startswith(self.module + "/"):
             return self.load(path[len(self.module) + 1:])
+        for prefix, root in getattr(self, "extra_roots", {}).items():       # e.g. the shim's module: its packages live under shim/go/
+            if path.startswith(prefix + "/"):
+                return self.load_dir(path, os.path.join(root, path[len(prefix) + 1:]))
         raise Unsupported(f"package {path!r} is not available to the interpreter")
+
+    def load_dir(self, path, d):
+        if path in self.pkgs:
+            return self.pkgs[path]
+        pkg = Pkg(path, os.path.basename(d))
+        self.pkgs[path] = pkg
+        for fname, src in gocheck.read_dir(d):
+            self._add_file(pkg, gocheck.parse_source(src, fname, bodies=False))
+        return pkg
 
     def ensure_init(self, pkg):
         if pkg.initialised:
@@ -361,7 +381,7 @@ class Interp:
                 return ""
             return None
         if k == "struct":
-            return GoStruct(rt, {n: self.zero(ft) for n, ft in rt.fields})
+            return GoStruct(rt, {(n if n is not None else self.embedded_name(ft)): self.zero(ft) for n, ft in rt.fields})
         if k == "array":
             return GoArray([self.zero(rt.elem) for _ in range(rt.n)], 0, rt.n, rt.elem)
         return None                                       # ptr, slice, map, func, iface, typeparam
@@ -369,7 +389,7 @@ class Interp:
     @staticmethod
     def embedded_name(ft):
         t = ft.elem if ft.kind == "ptr" else ft
-        return t.name
+        return t.name or getattr(t, "_stub", None) or "embedded"
 
     def convert(self, rt, v):
         """T(v)."""
@@ -494,7 +514,17 @@ class Interp:
         t = mk("time")
         t.native.update({"Now": Builtin(lambda a: 0, "Now"), "Since": Builtin(lambda a: 0, "Since")})
         rt_ = mk("runtime")
-        rt_.native.update({"NumCPU": Builtin(lambda a: 1, "NumCPU"), "GOMAXPROCS": Builtin(lambda a: 1, "GOMAXPROCS")})
+        rt_.native.update({"NumCPU": Builtin(lambda a: 1, "NumCPU"), "GOMAXPROCS": Builtin(lambda a: 1, "GOMAXPROCS"),
+                           "LockOSThread": Builtin(lambda a: None, "LockOSThread"), "UnlockOSThread": Builtin(lambda a: None, "UnlockOSThread")})
+        at = mk("sync/atomic", "atomic")
+
+        def add_u32(a):
+            v = np.uint32(int(ptr_load(a[0])) + int(a[1]))
+            ptr_store(a[0], v)
+            return v
+        at.native["AddUint32"] = Builtin(add_u32, "AddUint32")
+        for nme in ("WaitGroup", "Mutex", "RWMutex", "Pool"):
+            s.native[nme]._stub = nme
 
     @staticmethod
     def sprintf(a):
@@ -849,6 +879,9 @@ class Interp:
             if isinstance(p, VarPtr):
                 p.env.vars[p.name] = self.like(p.env.vars[p.name], v)
                 return
+            if isinstance(p, FieldPtr):
+                p.s.f[p.name] = self.like(p.s.f[p.name], v, self.field_type(p.s, p.name))
+                return
         if k == "paren":
             return self.store(lhs.x, v, env)
         raise Unsupported(f"assignment target {k}")
@@ -1020,6 +1053,10 @@ class Interp:
                     return GoFunc(decl, None, t.pkg, recv=x if isinstance(x, GoPtr) else target, name=name)
             for fn, fv in target.f.items():                      # promoted through an embedded struct
                 inner = fv.v if isinstance(fv, GoPtr) else fv
+                if isinstance(inner, GoStruct):
+                    nm = self.native_method(inner, name)
+                    if nm is not None:
+                        return Builtin(nm, name)
                 if isinstance(inner, GoStruct) and inner.t.kind == "named" and inner.t.name == fn:
                     try:
                         return self.member(fv, name, node)
@@ -1051,6 +1088,11 @@ class Interp:
                 return GoPtr(v)
             if t.kind == "ident":
                 return VarPtr(env.find(t.name), t.name)
+            if t.kind == "selector":
+                owner = self.eval(t.x, env)
+                owner = owner.v if isinstance(owner, GoPtr) else owner
+                if isinstance(owner, GoStruct) and t.sel in owner.f:
+                    return FieldPtr(owner, t.sel)
             raise Unsupported(f"address of this expression (line {e.line})")
         if op == "*":
             v = self.eval(e.x, env)
@@ -1062,6 +1104,8 @@ class Interp:
                 return v.a[v.i]
             if isinstance(v, VarPtr):
                 return v.env.vars[v.name]
+            if isinstance(v, FieldPtr):
+                return v.s.f[v.name]
             raise GoPanic(f"nil pointer dereference (line {e.line})")
         v = self.eval(e.x, env)
         if op == "-":
@@ -1323,6 +1367,29 @@ class Interp:
 
 
 BUILTINS = {"len", "cap", "make", "new", "append", "copy", "panic", "real", "imag", "complex", "delete", "recover", "print", "println", "min", "max"}
+
+
+def ptr_load(p):
+    if isinstance(p, VarPtr):
+        return p.env.vars[p.name]
+    if isinstance(p, FieldPtr):
+        return p.s.f[p.name]
+    if isinstance(p, ElemPtr):
+        return p.a[p.i]
+    if isinstance(p, GoPtr):
+        return p.v
+    raise GoPanic("load through a nil pointer")
+
+
+def ptr_store(p, v):
+    if isinstance(p, VarPtr):
+        p.env.vars[p.name] = v
+    elif isinstance(p, FieldPtr):
+        p.s.f[p.name] = v
+    elif isinstance(p, ElemPtr):
+        p.a[p.i] = v
+    else:
+        raise GoPanic("store through a nil pointer")
 
 
 # ------------------------------------------------------------------------------------------------------- numpy bridges
