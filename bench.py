@@ -89,6 +89,60 @@ def measured_traffic_uint5(kernel):
         return None
 
 
+_LIVE_PMC = {}
+LIVE_PMC_UINT5 = True
+
+
+def live_pmc(pset, batch, kernel_substr, timeout_s=150):
+    """HBM traffic of one kernel collected BY THIS RUN: tools/pmc_workload.py <pset> <batch> under `rocprofv3 --kernel-trace --pmc
+    FETCH_SIZE` and, in a pass of its own, `--pmc WRITE_SIZE` (the micro-architecture guide's recipe: separate passes, kernel trace
+    only; FETCH_SIZE x 2 on gfx950), as subprocesses after the timed regions.  Returns {FETCH_SIZE_KiB, WRITE_SIZE_KiB,
+    hbm_bytes_per_launch, launches, ...} or {"error": ...} (rocprofv3 missing, refused, timed out: the committed pass is then reported
+    instead, marked as such).  Rank 0 of an N = 1 run only; ~10 s per pass at the 128-bit set, ~25 s at Uint5 (1.7 GB of random key)."""
+    key = (pset, batch, kernel_substr)
+    if key in _LIVE_PMC:
+        return _LIVE_PMC[key]
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rec = {}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        rec = {"error": "rocprofv3 not found"}
+    else:
+        tmp = tempfile.mkdtemp(prefix="tfhe_pmc_", dir="/tmp")
+        try:
+            vals = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(tmp, ctr)
+                env = dict(os.environ, TMPDIR="/tmp")
+                r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "--", sys.executable,
+                                    os.path.join(ROOT, "tools", "pmc_workload.py"), pset, str(batch), "4"],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+                got = []
+                for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row.get("Counter_Name") == ctr and kernel_substr in row.get("Kernel_Name", ""):
+                            got.append(float(row["Counter_Value"]))
+                if not got:
+                    raise RuntimeError(f"no {ctr} rows for {kernel_substr} (rocprofv3 rc {r.returncode}: {(r.stderr or r.stdout)[-200:]!r})")
+                got = got[1:] if len(got) > 1 else got          # drop the first-touch launch
+                vals[ctr] = (sum(got) / len(got), len(got))
+            f_kib, w_kib = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+            rec = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "hbm_bytes_per_launch": (2.0 * f_kib + w_kib) * 1024.0,
+                   "launches": vals["FETCH_SIZE"][1], "correction": "2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md) + WRITE_SIZE, x 1024",
+                   "workload": f"tools/pmc_workload.py {pset} {batch} (random key; traffic is value-independent)",
+                   "how": "collected by THIS run: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE / WRITE_SIZE) as subprocesses after the timed regions"}
+        except Exception as e:                                   # noqa: BLE001 -- a measurement helper never fails the bench
+            rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    _LIVE_PMC[key] = rec
+    return rec
+
+
 def fp64_flops_per_bootstrap(p):
     """n x (2L+2 transforms x 5*(N/2)*log2(N/2) + 4L*(N/2)*8)."""
     M = p.N // 2
@@ -432,6 +486,15 @@ def keyswitch_hbm_record(p, B, ks_ms, ceil):
     except Exception:
         pass
     m = measured_traffic_uint5("k_keyswitch")
+    live = live_pmc("uint5", B, "k_keyswitch_wide") if LIVE_PMC_UINT5 else {"error": "live collection switched off"}
+    if "error" not in live:
+        rec["measured"] = {**live, "ratio_to_compulsory": live["hbm_bytes_per_launch"] / comp,
+                           "source": "collected by this run (rocprofv3 subprocess passes)",
+                           "committed_pass_for_comparison": {"hbm_bytes_per_launch": m.get("hbm_bytes_per_launch") if m else None, "file": "profiles/pmc_traffic_uint5.json"},
+                           "write_side_note": "WRITE_SIZE counts every 32-bit atomic of the partial sums as a memory-side request of 8 B per lane (profiles/r05_d_ks_xcd_sum.txt): "
+                                              "197.6 MB for 2.2 MB of modified words, whichever XCD issues them"}
+        return rec
+    rec["live_collection_error"] = live["error"]
     if m:
         rec["measured"] = {"FETCH_SIZE_KiB": m.get("FETCH_SIZE_KiB"), "WRITE_SIZE_KiB": m.get("WRITE_SIZE_KiB"),
                            "hbm_bytes_per_launch": m.get("hbm_bytes_per_launch"), "correction": m.get("correction"),
@@ -555,12 +618,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3/4/5 and the ceiling micro-benchmarks after the headline")
+    ap.add_argument("--no-live-pmc", action="store_true", help="report the committed rocprofv3 PMC passes instead of collecting FETCH_SIZE / WRITE_SIZE in this run")
     ap.add_argument("--mode", choices=["weak", "sharded"], default="weak")
     ap.add_argument("--workload", choices=["mixed", "adder"], default="mixed", help="--mode sharded only")
     ap.add_argument("--gates", type=int, default=0, help="--mode sharded --workload mixed: total gates (default 131072 per rank)")
     ap.add_argument("--config5-gates", type=int, default=1048576,
                     help="N > 1: size of the sharded mixed stream run after the headline (BASELINE configs[4] is 1M gates; smaller only for dry runs)")
     args = ap.parse_args()
+    global LIVE_PMC_UINT5
+    LIVE_PMC_UINT5 = not args.no_live_pmc
     claim_stdout()
 
     import torch
@@ -716,6 +782,14 @@ def main():
         stream_gbs = alg / (br_avg_ms * 1e-3) / 1e9
         tflops = fp64_flops_per_bootstrap(p) * BATCH / (br_avg_ms * 1e-3) / 1e12
         traffic = measured_traffic("k_blind_rotate")
+        traffic_src = traffic_source()
+        if world == 1 and not args.no_configs and not args.no_live_pmc:
+            live = live_pmc("128", BATCH, "k_blind_rotate<")
+            if "error" not in live:
+                traffic_src = {"collected_by_this_run": True, **live, "committed_pass_for_comparison": {"bytes": traffic, **traffic_src}}
+                traffic = live["hbm_bytes_per_launch"]
+            else:
+                traffic_src = {"collected_by_this_run": False, "live_collection_error": live["error"], **traffic_src}
         ks_alg = algorithmic_bytes_keyswitch(p) * BATCH
         line = {
             "metric": "gate bootstraps/sec (NAND, 128-bit params)",
@@ -729,7 +803,7 @@ def main():
                        "control_backend": "gloo" if dist else None,
                        "inputs": "real encryptions of random bits under a seeded key (harness PRNG)"},
             "roofline": {"kernel": "k_blind_rotate", "bound": "fp64_valu", "achieved": tflops, "peak": FP64_VECTOR_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source(),
+                         "unit": "TFLOP/s", "frac": tflops / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": fp64_flops_per_bootstrap(p) * BATCH,
                          "flops_note": "SURVEY 8d's radix-2 operation count (1,824 flop per lane and CMUX step); the radix-8 kernel executes 1,686, so "
                                        "`achieved` overstates executed flops by 8 % (the usual convention: algorithmic work over time)",
