@@ -296,3 +296,41 @@ def test_live_the_references_transform_under_the_interpreter_equals_the_oracle(o
     assert np.array_equal(got, oracle.to_fourier(p)) and np.array_equal(got, f["spectra_1024"][0])
     assert int(I.call_func("utils", "F64ToTorus", 0.125)) == 0x20000000 and int(I.call_func("utils", "F64ToTorus", -0.125)) == 0xE0000000
     assert math.isclose(I.steps, I.steps)
+
+
+FAST_REFERENCE_TESTS = {"utils": None, "lut": None, "tlwe": None, "poly": {"TestFFTRoundTrip", "TestPolyMul"},
+                        "params": {"TestSecurityLevelSwitching", "TestParameterConsistency", "TestSecurityInfo", "TestKSKAndBSKAlpha"}}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/poly"), reason="/root/reference is absent (GPU box)")
+@pytest.mark.parametrize("pkg_name", sorted(FAST_REFERENCE_TESTS))
+def test_the_references_own_unit_tests_pass_under_the_interpreter(pkg_name):
+    """The interpreter is pinned by the reference's OWN tests: utils_test.go (the F64ToTorus known answers, utils_test.go:15-20),
+    params_test.go, lut_test.go + analysis / debug / reference_algorithm tests (exact table layouts), poly_test.go (FFT round trip,
+    poly_test.go:10-33), tlwe_test.go (encrypt / decrypt / add / neg at the full 128-bit LWE dimension) run LIVE here, unmodified,
+    with a testing.T stand-in; the slow ones (gates_test.go, programmable_bootstrap_test.go: a cloud key per test) are run offline at a
+    reduced LWE dimension and recorded (next test)."""
+    import gointerp as gi
+    I = gi.Interp("/root/reference", seed=0x7F4E0101)
+    res = I.run_reference_tests(pkg_name, FAST_REFERENCE_TESTS[pkg_name])
+    assert res, f"no Test* functions found in {pkg_name}"
+    want = {"utils": 2, "params": 4, "lut": 10, "poly": 2, "tlwe": 5}[pkg_name]
+    assert len(res) >= want, sorted(res)
+    bad = {k: v["failures"] for k, v in res.items() if v["failures"]}
+    assert not bad, bad
+    assert all(v["statements"] > 0 for v in res.values())
+
+
+def test_recorded_runs_of_the_references_slow_unit_tests():
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "goref", "reference_tests.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/goref/reference_tests.json not generated (make_goref_vectors.py --jobs reference_tests)")
+    rec = json.load(open(path))
+    assert "NOT the Go toolchain" in rec["what"]
+    gates = rec["packages"]["gates"]["tests"]
+    for name in ("TestNAND", "TestAND", "TestOR", "TestXOR", "TestXNOR", "TestNOR", "TestMUX", "TestBatchAND", "TestBatchOR", "TestBatchXOR"):
+        assert name in gates, sorted(gates)
+    for pkg_name, p in rec["packages"].items():
+        bad = {k: v["failures"] for k, v in p["tests"].items() if v["failures"]}
+        assert not bad, (pkg_name, bad)

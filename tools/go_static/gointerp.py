@@ -47,6 +47,14 @@ class GoPanic(Exception):
     pass
 
 
+class TestFatal(Exception):
+    """t.Fatal / t.Fatalf / t.FailNow / t.Skip inside a reference test function."""
+
+    def __init__(self, skipped=False):
+        super().__init__("test stopped")
+        self.skipped = skipped
+
+
 class Unsupported(Exception):
     pass
 
@@ -516,6 +524,12 @@ class Interp:
         rt_ = mk("runtime")
         rt_.native.update({"NumCPU": Builtin(lambda a: 1, "NumCPU"), "GOMAXPROCS": Builtin(lambda a: 1, "GOMAXPROCS"),
                            "LockOSThread": Builtin(lambda a: None, "LockOSThread"), "UnlockOSThread": Builtin(lambda a: None, "UnlockOSThread")})
+        tst = mk("testing")
+        self.TEST_T = RT("struct", fields=[("name", BASIC_RT["string"])])
+        self.TEST_T._stub = "T"
+        tst.native["T"] = self.TEST_T
+        tst.native["B"] = RT("struct", fields=[])
+        tst.native["Short"] = Builtin(lambda a: False, "Short")
         at = mk("sync/atomic", "atomic")
 
         def add_u32(a):
@@ -528,9 +542,21 @@ class Interp:
 
     @staticmethod
     def sprintf(a):
+        import re as _re
         try:
-            fmt = a[0].replace("%v", "%s").replace("%d", "%s")
-            return fmt % tuple(str(x) for x in a[1:])
+            args = list(a[1:])
+
+            def sub(m):
+                if m.group(0) == "%%":
+                    return "%"
+                v = args.pop(0) if args else "%!MISSING"
+                verb = m.group(0)[-1]
+                if verb in "xX" and not isinstance(v, (str, float)):
+                    return format(int(v), m.group(0)[1:-1] + verb)
+                if verb in "feg" and isinstance(v, (int, float, np.generic)):
+                    return format(float(v), m.group(0)[1:-1] + verb if m.group(0)[1:-1] else ".6f")
+                return str(v)
+            return _re.sub(r"%[-+0-9. #]*[vdsfxXtqeg%T]", sub, a[0])
         except Exception:                               # noqa: BLE001
             return str(a)
 
@@ -543,6 +569,30 @@ class Interp:
                     "Int63": lambda a: int(self.rng.randint(0, 1 << 62)),
                     "Float64": lambda a: float(self.rng.random_sample()),
                     "NormFloat64": lambda a: float(self.rng.standard_normal())}.get(name)
+        if t is getattr(self, "TEST_T", None):
+            log = recv.f.setdefault("$log", {"failures": [], "logs": []})
+
+            def fail(a, fatal=False):
+                log["failures"].append(self.sprintf(a) if a and isinstance(a[0], str) and "%" in a[0] else " ".join(str(x) for x in a))
+                if fatal:
+                    raise TestFatal()
+
+            def run_sub(a):
+                sub = GoPtr(GoStruct(self.TEST_T, {"name": recv.f["name"] + "/" + str(a[0]), "$log": log}))
+                try:
+                    self.call(a[1], [sub])
+                except TestFatal:
+                    pass
+                return True
+
+            def skip(a):
+                log["logs"].append("SKIP " + " ".join(str(x) for x in a))
+                raise TestFatal(skipped=True)
+            return {"Errorf": lambda a: fail(a), "Error": lambda a: fail(a), "Fatalf": lambda a: fail(a, True), "Fatal": lambda a: fail(a, True),
+                    "Fail": lambda a: fail(["Fail()"]), "FailNow": lambda a: fail(["FailNow()"], True),
+                    "Logf": lambda a: log["logs"].append(self.sprintf(a)), "Log": lambda a: log["logs"].append(" ".join(str(x) for x in a)),
+                    "Run": run_sub, "Skip": skip, "Skipf": skip, "SkipNow": skip, "Helper": lambda a: None, "Name": lambda a: recv.f["name"],
+                    "Parallel": lambda a: None, "Cleanup": lambda a: None}.get(name)
         sync = self.pkgs["sync"]
         if t is sync.native["WaitGroup"]:
             return (lambda a: None) if name in ("Add", "Done", "Wait") else None
@@ -561,6 +611,48 @@ class Interp:
         pkg = self.pkgs.get(f"{self.module}/{pkg_name}") or self.load(pkg_name)
         self.ensure_init(pkg)
         return self.call_decl(pkg.funcs[func], pkg, list(args), None)
+
+    def run_reference_tests(self, pkg_name, only=None):
+        """Runs the reference's own Test* functions of one package (its *_test.go files: `package x` tests join the package, `package
+        x_test` tests become a package of their own that imports it) with a testing.T stand-in.  Returns {test name: {"failures": [...],
+        "skipped": bool, "statements": n}}; a test that panics is reported as a failure with the panic's message."""
+        pkg = self.load(pkg_name)
+        d = os.path.join(self.root, pkg_name)
+        ext = None
+        loaded = getattr(pkg, "_tests_loaded", False)
+        if not loaded:
+            pkg._tests_loaded = True
+            for f in sorted(os.listdir(d)):
+                if not f.endswith("_test.go"):
+                    continue
+                ast = gocheck.parse_source(open(os.path.join(d, f)).read(), os.path.join(d, f), bodies=False)
+                if ast.package == pkg_name or ast.package == pkg.name:
+                    self._add_file(pkg, ast)
+                else:
+                    ext = self.pkgs.get(pkg.path + "_test") or Pkg(pkg.path + "_test", ast.package)
+                    self.pkgs[pkg.path + "_test"] = ext
+                    self._add_file(ext, ast)
+        ext = self.pkgs.get(pkg.path + "_test")
+        out = {}
+        for host in [p for p in (pkg, ext) if p is not None]:
+            self.ensure_init(host)
+            for name, decl in sorted(host.funcs.items()):
+                if not name.startswith("Test") or len(decl.sig.params) != 1 or (only and name not in only):
+                    continue
+                if not getattr(decl._file[0], "fname", "").endswith("_test.go"):
+                    continue
+                t = GoPtr(GoStruct(self.TEST_T, {"name": name}))
+                s0 = self.steps
+                skipped = False
+                try:
+                    self.call_decl(decl, host, [t], None)
+                except TestFatal as e:
+                    skipped = e.skipped
+                except GoPanic as e:
+                    t.v.f.setdefault("$log", {"failures": [], "logs": []})["failures"].append(f"panic: {e}")
+                log = t.v.f.get("$log", {"failures": [], "logs": []})
+                out[name] = {"failures": list(log["failures"]), "skipped": skipped, "statements": self.steps - s0}
+        return out
 
     def call_method(self, recv, name, *args):
         fn = self.member(recv, name, None)

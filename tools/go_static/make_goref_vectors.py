@@ -355,6 +355,24 @@ def job_refkeygen(_):
                      "key generation, encryption and decryption at the 128-bit ring with the LWE dimension set to 2; randomness from the interpreter's seeded math/rand"))
 
 
+def job_reference_tests(_):
+    """The reference's OWN unit tests of the slow packages, run under the interpreter with the LWE dimension set to 2 (every test generates
+    a cloud key: cloudkey.NewCloudKey at n = 700 is hours of interpretation): gates/gates_test.go and evaluator/programmable_bootstrap_test.go.
+    The fast packages (utils, params, lut, poly, tlwe) are run live by tests/test_gointerp_semantics.py."""
+    out = {}
+    for pkg_name in ("gates", "evaluator"):
+        R = Ref("128", n_override=2, seed=0x7F4E00F3)
+        t0 = time.time()
+        res = R.I.run_reference_tests(pkg_name)
+        out[pkg_name] = {"n_override": 2, "seconds": round(time.time() - t0), "tests": res}
+        print(f"[goref] reference tests of {pkg_name}: {sum(1 for v in res.values() if not v['failures'])}/{len(res)} pass, {time.time() - t0:.0f} s", flush=True)
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "reference_tests.json"), "w") as fh:
+        json.dump({"what": "go-tfhe's own Test* functions executed by tools/go_static/gointerp.py (NOT the Go toolchain), 128-bit ring, LWE dimension set to 2",
+                   "packages": out}, fh, indent=1)
+    print("[goref] wrote tests/golden/goref/reference_tests.json", flush=True)
+
+
 # ------------------------------------------------------------------------------------------------------------------ full-size jobs
 
 def full_key_128():
@@ -442,7 +460,7 @@ def job_full(spec):
 
 
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
-         "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen}
+         "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
        [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)]
 
