@@ -36,8 +36,11 @@ OUT = os.path.join(ROOT, "tests", "golden", "goref")
 KEY_SEED_128 = 0x7F4E0002          # = tests/conftest.py keys128: the GPU tier already has this key on the device
 KEY_SEED_SMALL = 0x7F4E0003        # = tests/conftest.py keys_small (n = 24)
 KEY_SEED_UINT5 = 0x7F4E0091
-LEVELS = {"128": "Security128Bit", "80": "Security80Bit", "uint5": "SecurityUint5"}
-PARAM_VARS = {"128": "params128Bit", "80": "params80Bit", "uint5": "paramsUint5"}
+LEVELS = {"128": "Security128Bit", "80": "Security80Bit", "110": "Security110Bit", "uint5": "SecurityUint5", "uint1": "SecurityUint1", "uint2": "SecurityUint2",
+          "uint3": "SecurityUint3", "uint4": "SecurityUint4"}
+PARAM_VARS = {"128": "params128Bit", "80": "params80Bit", "110": "params110Bit", "uint5": "paramsUint5", "uint1": "paramsUint1", "uint2": "paramsUint2",
+              "uint3": "paramsUint3", "uint4": "paramsUint4"}
+KEY_SEED_80 = 0x7F4E0001           # = tests/conftest.py keys80
 
 
 class LazyRows:
@@ -209,6 +212,42 @@ def job_decompose_rotate(_):
     ds = np.array([0.125, -0.125, 0.25, -0.25, 0.5, -0.5, 0.75, 1.0, 0.0, 1e-9, -1e-9, 0.3, -0.7, 2.0e-5, 3.0e-8])
     out["f64"], out["f64_to_torus"] = ds, np.array([R.I.call_func("utils", "F64ToTorus", float(d)) for d in ds], np.uint32)
     save("decompose_rotate", **out)
+
+
+def job_other_shapes(_):
+    """The transform at N = 512 and decomposition + one external product at every other parameter shape of params.go (Uint1: L = 2, Bgbit = 10;
+    Uint2: N = 512, Bgbit = 18; Uint3: Bgbit = 23; Uint4 / Uint5: N = 2048, Bgbit = 22; 80- and 110-bit: the 128-bit ring)."""
+    o = oracle()
+    out = {}
+    R = Ref("uint2")
+    pe = R.I.call_func("poly", "NewEvaluator", 512)
+    rs = np.random.RandomState(512)
+    Poly = R.I.named(R.pk["poly"], "Poly")
+    polys = np.stack([rs.randint(0, 2**32, 512, dtype=np.uint64).astype(np.uint32), np.full(512, 0x7FFFFFFF, np.uint32)])
+    out["polys_512"] = polys
+    out["spectra_512"] = np.stack([gi.slice_to_np(R.I.call_method(pe, "ToFourierPoly", gi.GoStruct(Poly, {"Coeffs": R.torus(p)})).f["Coeffs"], np.float64) for p in polys])
+    for level in ("uint1", "uint2", "uint3", "uint4", "80", "110"):
+        R = Ref(level, n_override=2)
+        g = R.I.call_func("params", "GetTRGSWLv1")
+        bgbit, L, N = int(g.f["BGBIT"]), R.L, R.N
+        p = o.params(level).small(2)
+        rng = o.rng(0x7F4E0200 + N + bgbit)
+        s0, s1 = o.keygen_secret(p, rng)
+        _, bsk_f = o.keygen_bsk(p, rng, s0, s1, torus=False, fourier=True)
+        rs = np.random.RandomState(N + bgbit)
+        tin = rs.randint(0, 2**32, (2, N), dtype=np.uint64).astype(np.uint32)
+        outs = [gi.GoStruct(Poly, {"Coeffs": R.torus(np.zeros(N, np.uint32))}) for _ in range(L)]
+        PolyT = R.I.named(R.pk["poly"], "Poly")
+        outs = [gi.GoStruct(PolyT, {"Coeffs": R.torus(np.zeros(N, np.uint32))}) for _ in range(L)]
+        R.I.call_func("poly", "DecomposePolyAssign", R.torus(tin[0]), bgbit, L, R.offset, gi.GoSlice(outs, 0, L, L, PolyT))
+        ev = R.I.call_func("evaluator", "NewEvaluator", N)
+        cout = R.new_trlwe()
+        R.I.call_method(ev, "ExternalProductAssign", R.trgsw_fft_from_arrays(bsk_f[0]), R.trlwe(tin), R.offset, cout)
+        out[f"in_{level}"], out[f"dec_{level}"], out[f"extprod_{level}"] = tin, np.stack([R.u32(x.f["Coeffs"]) for x in outs]), R.trlwe_np(cout)
+        out[f"offset_{level}"], out[f"seed_{level}"] = np.uint32(R.offset), np.int64(0x7F4E0200 + N + bgbit)
+        out["meta"] = R.meta("poly.Evaluator.ToFourierPoly at N = 512; poly.DecomposePolyAssign + Evaluator.ExternalProductAssign at the Uint1 / Uint2 / Uint3 / Uint4 and "
+                             "80- / 110-bit parameter shapes (keys from the oracle harness at n = 2, seed 0x7F4E0200 + N + Bgbit)")
+    save("other_shapes", **out)
 
 
 def job_extprod_chain(_):
@@ -416,6 +455,23 @@ def job_full(spec):
             save(f"full128_gate_{arg}", a=a[i], b=b[i], c=c[i], bits=bits[:, i].astype(np.uint8), out=R.u32(r.v.f["P"]),
                  meta=R.meta(f"gates.{arg} (gates/gates.go) at the FULL 128-bit set (n = 700, N = 1024) with keys128 (seed 0x7F4E0002); inputs from the oracle "
                              "harness, seed 0x7F4E00C3"))
+    elif kind == "gate80":
+        # BASELINE configs[0]: "single NAND gate, 80-bit params (N = 1024), pure-Go CPU path" -- here it is, from the reference's source, at full size
+        o = oracle()
+        p = o.params("80")
+        rng = o.rng(KEY_SEED_80)
+        s0, s1 = o.keygen_secret(p, rng)
+        _, bsk_f = o.keygen_bsk(p, rng, s0, s1, torus=True, fourier=True)
+        ksk = o.keygen_ksk(p, rng, s0, s1)
+        erng = o.rng(0x7F4E00C9)
+        bits = np.array([[1], [1]])
+        a, b = (o.encrypt_bools(p, erng, bits[k], s0) for k in range(2))
+        R = Ref("80")
+        ck = R.cloudkey(bsk_f, ksk)
+        r = R.I.call_func("gates", arg, R.lwe(a[0]), R.lwe(b[0]), ck)
+        save(f"full80_gate_{arg}", a=a[0], b=b[0], bits=bits[:, 0].astype(np.uint8), out=R.u32(r.v.f["P"]),
+             meta=R.meta(f"gates.{arg} at the FULL 80-bit set (n = 550, N = 1024: BASELINE configs[0]) with keys80 (tests/conftest.py, seed 0x7F4E0001); inputs from the "
+                         "oracle harness, seed 0x7F4E00C9"))
     elif kind == "ingest":
         # the reference's key ingest over a whole slice of the full key: trgsw.NewTRGSWLv1FFT(bsk_torus[i]) == the oracle's Fourier key, bit for bit
         o, p, rng, s0, s1, bsk_t, bsk_f, ksk = full_key_128()
@@ -460,9 +516,9 @@ def job_full(spec):
 
 
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
-         "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests}
+         "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
-       [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)]
+       [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND")]
 
 
 def run_small(name):
