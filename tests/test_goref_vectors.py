@@ -164,6 +164,34 @@ def test_oracle_bootstraps_and_gates_equal_the_reference_source_n24(oracle, keys
 FULL_GATES = GATES2 + ["MUX"]
 
 
+def test_oracle_equals_the_reference_source_at_every_other_parameter_shape(oracle):
+    # N = 512 transform; decomposition + one external product at Uint1 (L = 2, Bgbit = 10), Uint2 (N = 512, Bgbit = 18), Uint3 (Bgbit = 23),
+    # Uint4 (N = 2048, Bgbit = 22) and the 80- / 110-bit sets.  The oracle runs the same operations on the same doubles as the reference's
+    # source, so even where the arithmetic is not exact (the Uint shapes) the words are identical -- the tolerance regime of SURVEY.md 8c(4)
+    # concerns OTHER fp64 pipelines (the HIP kernels' radix-8 transforms), not this restatement
+    z = load("other_shapes")
+    for i in range(len(z["polys_512"])):
+        assert np.array_equal(oracle.to_fourier(z["polys_512"][i]), z["spectra_512"][i]), i
+    for level in ("uint1", "uint2", "uint3", "uint4", "80", "110"):
+        p = oracle.params(level).small(2)
+        assert oracle.offset(p) == int(z[f"offset_{level}"]), level
+        rng = oracle.rng(int(z[f"seed_{level}"]))
+        s0, s1 = oracle.keygen_secret(p, rng)
+        _, bsk_f = oracle.keygen_bsk(p, rng, s0, s1, torus=False, fourier=True)
+        tin = z[f"in_{level}"]
+        assert np.array_equal(oracle.decompose(p, tin[0]), z[f"dec_{level}"]), level
+        assert np.array_equal(oracle.external_product(p, bsk_f[0], tin), z[f"extprod_{level}"]), level
+
+
+def test_oracle_full_size_80bit_nand_equals_the_reference_source(oracle, keys80):
+    # BASELINE configs[0]: "single NAND gate, 80-bit params (N = 1024), pure-Go CPU path" -- executed from the reference's source at full size
+    f = load("full80_gate_NAND")
+    k = keys80
+    got = oracle.gate(k.p, k.bsk, k.ksk, "NAND", f["a"], f["b"])
+    assert np.array_equal(got, f["out"])
+    assert bool(k.dec(got[None])[0]) == (not (bool(f["bits"][0]) and bool(f["bits"][1])))
+
+
 def test_oracle_full_size_bootstraps_equal_the_reference_source(oracle, keys128):
     k = keys128
     seen = 0
@@ -301,6 +329,28 @@ def test_gpu_full_size_bootstraps_and_gates_equal_the_reference_source(pkg, keys
             seen += 1
     if not seen:
         pytest.skip("no full-size vectors (make_goref_vectors.py --jobs full)")
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_80bit_nand_equals_the_reference_source(pkg, keys80, ck80):
+    f = load("full80_gate_NAND")                            # BASELINE configs[0] on the engine
+    assert np.array_equal(ck80.ctx.gate_batch("NAND", f["a"][None], f["b"][None])[0], f["out"])
+
+
+@pytest.mark.gpu
+def test_gpu_external_products_at_the_other_exact_shapes_equal_the_reference_source(pkg, oracle):
+    from conftest import gpu_params
+    z = load("other_shapes")
+    for level in ("80", "110"):                             # exact regime: words; the Uint shapes are covered by their own tolerance tests
+        p = oracle.params(level).small(2)
+        rng = oracle.rng(int(z[f"seed_{level}"]))
+        s0, s1 = oracle.keygen_secret(p, rng)
+        _, bsk_f = oracle.keygen_bsk(p, rng, s0, s1, torus=False, fourier=True)
+        ck = pkg.CloudKey(gpu_params(pkg, p), bsk_fourier=bsk_f, ksk=np.zeros((p.ksk_rows, p.n + 1), np.uint32))
+        try:
+            assert np.array_equal(ck.ctx.external_product_batch(0, z[f"in_{level}"][None])[0], z[f"extprod_{level}"]), level
+        finally:
+            ck.close()
 
 
 @pytest.mark.gpu
