@@ -180,6 +180,27 @@ def test_go_golden_program_type_checks():
     assert any("cannot use" in e for e in errs), errs
 
 
+def test_go_golden_program_has_been_executed_and_its_dump_checked():
+    # tools/go_golden/main.go run by the interpreter at a reduced LWE dimension (tools/go_static/make_goref_vectors.py --jobs go_golden_program):
+    # every file of its documented schema was written and read back by numpy, and tests/test_go_golden.py passed on them
+    import hashlib
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "goref", "go_golden_program_run.json")
+    if not os.path.exists(path):
+        pytest.skip("no recorded run of tools/go_golden/main.go under the interpreter")
+    rec = json.load(open(path))
+    assert rec["main_go_sha256"] == hashlib.sha256(open(os.path.join(ROOT, "tools", "go_golden", "main.go"), "rb").read()).hexdigest(), \
+        "tools/go_golden/main.go changed since its recorded run: python tools/go_static/make_goref_vectors.py --jobs go_golden_program"
+    assert rec["pytest_returncode"] == 0 and not any(l.startswith(("FAILED", "ERROR")) for l in rec["pytest_results"]), rec["pytest_results"]
+    passed = [l for l in rec["pytest_results"] if l.startswith("PASSED")]
+    assert len(passed) >= 5, rec["pytest_results"]
+    f = rec["files_written"]
+    for name in ("small/params.npy", "small/extprod_out.npy", "small/cmux_acc.npy", "big/lwe_out.npy", "big/gate_MUX.npy", "small/uint5_lut_identity.npy",
+                 "big/uint5/pbs_out.npy", "big/uint5/ksk.npy"):
+        assert name in f, sorted(f)
+    assert f["small/extprod_out.npy"] == {"dtype": "uint32", "shape": [2, 1024]} and f["small/uint5_lut_ge16.npy"]["shape"] == [2, 2048]
+
+
 def test_integration_md_shows_the_shim_files_verbatim():
     import sync_integration_md as sync
     doc = _read("INTEGRATION.md")

@@ -450,6 +450,9 @@ class Interp:
                     raise GoPanic("pointer-to-array view past the end of the backing array")
                 return GoPtr(GoArray(v.a, v.i, arr.n, arr.elem))
             return v
+        if k == "slice" and isinstance(v, str):
+            vals = [np.uint8(b) for b in v.encode("utf-8")]
+            return GoSlice(vals, 0, len(vals), len(vals), u.elem)
         if k in ("slice", "struct", "map", "func", "iface", "array", "typeparam"):
             return v
         raise Unsupported(f"conversion to {rt}")
@@ -524,6 +527,47 @@ class Interp:
         rt_ = mk("runtime")
         rt_.native.update({"NumCPU": Builtin(lambda a: 1, "NumCPU"), "GOMAXPROCS": Builtin(lambda a: 1, "GOMAXPROCS"),
                            "LockOSThread": Builtin(lambda a: None, "LockOSThread"), "UnlockOSThread": Builtin(lambda a: None, "UnlockOSThread")})
+        # ---- what tools/go_golden/main.go needs to RUN under the interpreter (files really get written: numpy reads them back)
+        import struct as _struct
+        FILE = RT("struct", fields=[])
+        FILE._stub = "File"
+        self.FILE_T = FILE
+        osp = mk("os")
+        osp.native["File"] = FILE
+
+        def os_create(a):
+            return (GoPtr(GoStruct(FILE, {"$fh": open(a[0], "wb")})), None)
+        osp.native.update({"Create": Builtin(os_create, "Create"), "MkdirAll": Builtin(lambda a: os.makedirs(a[0], exist_ok=True), "MkdirAll")})
+        fp = mk("path/filepath", "filepath")
+        fp.native["Join"] = Builtin(lambda a: os.path.join(*a), "Join")
+        st = mk("strings")
+        st.native.update({"Join": Builtin(lambda a: a[1].join(a[0].a[a[0].o:a[0].o + a[0].n]), "Join"), "Repeat": Builtin(lambda a: a[0] * int(a[1]), "Repeat")})
+        m.native["Float64bits"] = Builtin(lambda a: _struct.unpack("<Q", _struct.pack("<d", float(a[0])))[0], "Float64bits")
+        ORDER = RT("struct", fields=[])
+        ORDER._stub = "littleEndian"
+        self.ORDER_T = ORDER
+        bn = mk("encoding/binary", "binary")
+        bn.native["LittleEndian"] = GoStruct(ORDER, {})
+
+        def bin_write(a):
+            v = a[2]
+            if isinstance(v, np.generic):
+                gi_bytes = v.tobytes()
+            else:
+                raise Unsupported("binary.Write of this value")
+            a[0].v.f["$fh"].write(gi_bytes)
+            return None
+        bn.native["Write"] = Builtin(bin_write, "Write")
+        fl = mk("flag")
+        self.flag_overrides = {}
+
+        def flag_var(a):
+            box = Env()
+            box.vars["v"] = self.flag_overrides.get(a[0], a[1])
+            return VarPtr(box, "v")
+        for nme in ("String", "Int", "Int64", "Bool", "Float64"):
+            fl.native[nme] = Builtin(flag_var, nme)
+        fl.native["Parse"] = Builtin(lambda a: None, "Parse")
         tst = mk("testing")
         self.TEST_T = RT("struct", fields=[("name", BASIC_RT["string"])])
         self.TEST_T._stub = "T"
@@ -563,6 +607,23 @@ class Interp:
     # native methods of the stub types
     def native_method(self, recv, name):
         t = recv.t if isinstance(recv, GoStruct) else None
+        if t is getattr(self, "FILE_T", None):
+            fh = recv.f["$fh"]
+
+            def fwrite(a):
+                v = a[0]
+                data = v.encode("latin-1") if isinstance(v, str) else bytes(int(x) & 0xFF for x in v.a[v.o:v.o + v.n])
+                fh.write(data)
+                return (len(data), None)
+            return {"Write": fwrite, "Close": lambda a: fh.close()}.get(name)
+        if t is getattr(self, "ORDER_T", None):
+            def put(nbytes):
+                def f(a):
+                    b, v = a[0], int(a[1])
+                    for k in range(nbytes):
+                        b.a[b.o + k] = np.uint8((v >> (8 * k)) & 0xFF)
+                return f
+            return {"PutUint32": put(4), "PutUint64": put(8), "PutUint16": put(2)}.get(name)
         if t is self.RAND:
             return {"Uint32": lambda a: np.uint32(self.rng.randint(0, 1 << 32, dtype=np.uint64)),
                     "Intn": lambda a: int(self.rng.randint(0, int(a[0]))),

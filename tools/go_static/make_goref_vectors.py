@@ -412,6 +412,48 @@ def job_reference_tests(_):
     print("[goref] wrote tests/golden/goref/reference_tests.json", flush=True)
 
 
+def job_go_golden_program(_):
+    """tools/go_golden/main.go -- the program that pins parity the day someone runs it with the Go toolchain -- EXECUTED by the interpreter
+    (os / flag / encoding/binary stand-ins; the LWE dimension of both parameter sets set to 2 so that cloudkey.NewCloudKey is minutes, not
+    hours), its .npy files read back by numpy, and tests/test_go_golden.py (CPU tier) run on them: the dump program itself is correct
+    (header writer, shapes, the order of the reference calls), not only type-correct.  The files are NOT committed (tests/golden/go/ is
+    reserved for what the Go toolchain writes); a summary is."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="go_golden_interp_")
+    I = gi.Interp(REF, seed=0x7F4E0111)
+    params = I.load("params")
+    I.pkg_value(params, "params128Bit").f["TLWELv0"].f["N"] = 2
+    I.pkg_value(params, "paramsUint5").f["TLWELv0"].f["N"] = 2
+    I.flag_overrides = {"out": tmp, "batch": 2, "steps": 2, "uint5": True, "pbs": 3}
+    src = os.path.join(ROOT, "tools", "go_golden", "main.go")
+    pkg = I.load_source("main", {src: open(src).read()}, path="example.com/go_golden")
+    t0 = time.time()
+    I.call_decl(pkg.funcs["main"], pkg, [], None)
+    secs = time.time() - t0
+    files = {}
+    for sub in ("small", "big", os.path.join("big", "uint5")):
+        d = os.path.join(tmp, sub)
+        for f in sorted(os.listdir(d)):
+            if f.endswith(".npy"):
+                a = np.load(os.path.join(d, f))
+                files[os.path.join(sub, f)] = {"dtype": str(a.dtype), "shape": list(a.shape)}
+    env = dict(os.environ, TFHE_GO_GOLDEN_SMALL=os.path.join(tmp, "small"), TFHE_GO_GOLDEN_BIG=os.path.join(tmp, "big"))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_go_golden.py"), "-q", "-m", "not gpu", "-rA"],
+                       env=env, capture_output=True, text=True, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("PASSED", "FAILED", "SKIPPED", "ERROR"))]
+    rec = {"what": "tools/go_golden/main.go executed by tools/go_static/gointerp.py (NOT the Go toolchain) with the LWE dimension of the 128-bit and Uint5 sets set to 2; "
+                   "its output files read back and checked by tests/test_go_golden.py (CPU tier)",
+           "main_go_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(), "seconds": round(secs), "statements_executed": I.steps,
+           "files_written": files, "pytest_returncode": r.returncode, "pytest_results": lines, "pytest_tail": r.stdout.strip().splitlines()[-1:]}
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "go_golden_program_run.json"), "w") as fh:
+        json.dump(rec, fh, indent=1)
+    shutil.rmtree(tmp, ignore_errors=True)
+    print(f"[goref] go_golden main.go under the interpreter: {secs:.0f} s, pytest rc {r.returncode}: {rec['pytest_tail']}", flush=True)
+
+
 # ------------------------------------------------------------------------------------------------------------------ full-size jobs
 
 def full_key_128():
@@ -516,7 +558,8 @@ def job_full(spec):
 
 
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
-         "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes}
+         "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
+         "go_golden_program": job_go_golden_program}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
        [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND")]
 
