@@ -1,0 +1,6 @@
+// Stand-in for go-tfhe's poly package on the GPU box (tests/go_stubs/README.md).
+package poly
+
+type FourierPoly struct {
+	Coeffs []float64
+}

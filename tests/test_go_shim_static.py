@@ -201,6 +201,49 @@ def test_go_golden_program_has_been_executed_and_its_dump_checked():
     assert f["small/extprod_out.npy"] == {"dtype": "uint32", "shape": [2, 1024]} and f["small/uint5_lut_ge16.npy"]["shape"] == [2, 2048]
 
 
+@needs_ref
+def test_go_stubs_declare_what_the_reference_declares():
+    """tests/go_stubs/ (the reference's TYPES for the GPU box, where the shim is executed against the real library) against the
+    reference: every struct has the same fields with the same types, every function / method the same signature."""
+    import gocheck
+    w, ref = gocheck.build_world(REF, HDR)
+    stub_root = os.path.join(ROOT, "tests", "go_stubs")
+    stubs = {}
+    for d in sorted(os.listdir(stub_root)):
+        if os.path.isdir(os.path.join(stub_root, d)):
+            stubs[d], _ = w.load_package(f"stub.example/{d}", gocheck.read_dir(os.path.join(stub_root, d)), name_hint=d, bodies=True)
+    # the stubs import each other under the reference's paths: resolve those imports against the STUB packages
+    mod = "github.com/thedonutfactory/go-tfhe"
+    saved = {f"{mod}/{d}": w.by_path[f"{mod}/{d}"] for d in stubs}
+    for p in ref:
+        w.resolve_package(p, strict=False)
+    def norm(t):                                              # "stub.example/x.T" and the reference's "…/go-tfhe/x.T" name the same thing
+        if isinstance(t, tuple):
+            return tuple(norm(x) for x in t)
+        return t.replace("stub.example/", mod + "/") if isinstance(t, str) else t
+    for d in stubs:
+        w.by_path[f"{mod}/{d}"] = stubs[d]
+    for p in stubs.values():
+        w.resolve_package(p)
+    for d in stubs:
+        w.by_path[f"{mod}/{d}"] = saved[f"{mod}/{d}"]
+    assert not w.errors, w.errors
+    checked = 0
+    for d, sp in stubs.items():
+        rp = saved[f"{mod}/{d}"]
+        for name, (kind, t) in sp.types.items():
+            assert name in rp.types, f"{d}.{name} is not a type of the reference"
+            assert rp.types[name][0] == kind and norm(t) == norm(rp.types[name][1]), f"{d}.{name}: stub {t} vs reference {rp.types[name][1]}"
+            checked += 1
+        for name, ft in sp.funcs.items():
+            assert name in rp.funcs and norm(ft) == norm(rp.funcs[name]), f"{d}.{name}: signature differs from the reference's"
+            checked += 1
+        for key_, ft in sp.methods.items():
+            assert key_ in rp.methods and norm(ft) == norm(rp.methods[key_]), f"{d}.{key_}: signature differs from the reference's"
+            checked += 1
+    assert checked >= 20, checked
+
+
 def test_integration_md_shows_the_shim_files_verbatim():
     import sync_integration_md as sync
     doc = _read("INTEGRATION.md")

@@ -15,9 +15,115 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 OPNAMES = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX"]
 
 
+class OracleBackend:
+    """The entry points' arithmetic on the CPU oracle (CPU tier: validates the shim's logic, not the GPU library)."""
+
+    def __init__(self, oracle, device_count=2):
+        self.o, self.ndev = oracle, device_count
+
+    def device_count(self):
+        return self.ndev
+
+    def params(self, f):
+        n, N, L, Bg, bb, t = (int(f[k]) for k in ("n", "N", "L", "Bgbit", "basebit", "t"))
+        for name in ("80", "110", "128", "uint5", "uint1", "uint3", "uint4", "uint2"):
+            p = self.o.params(name)
+            if (p.N, p.L, p.Bgbit, p.basebit, p.t) == (N, L, Bg, bb, t):
+                return p.small(n)
+        raise MockError(-1, f"unsupported parameter shape N={N} L={L} Bgbit={Bg}")
+
+    def create(self, p, device):
+        return {"bsk": None, "ksk": None}
+
+    def destroy(self, h):
+        pass
+
+    def clone(self, h, device):
+        return {"bsk": h["bsk"], "ksk": h["ksk"]}, (1 if True else 2)
+
+    def load_bsk(self, h, p, arr):
+        h["bsk"] = arr
+
+    def load_ksk(self, h, p, arr):
+        h["ksk"] = arr
+
+    def _keys(self, h, need_ksk=True):
+        if h["bsk"] is None or (need_ksk and h["ksk"] is None):
+            raise MockError(-2, "cloud key not loaded")
+        return h["bsk"], h["ksk"]
+
+    def gate_batch(self, h, p, codes, A, B, C):
+        bsk, ksk = self._keys(h)
+        return self.o.gate_batch(p, bsk, ksk, codes, A, B, C)[0]
+
+    def bootstrap_batch(self, h, p, X, T):
+        bsk, ksk = self._keys(h)
+        return self.o.bootstrap_batch(p, bsk, ksk, X, T)[0]
+
+    def blind_rotate_batch(self, h, p, X, T, nsteps):
+        bsk, _ = self._keys(h, need_ksk=False)
+        return np.stack([self.o.blind_rotate(p, bsk, X[i], T, int(nsteps)) for i in range(len(X))])
+
+    def gate_testvec(self, p):
+        return self.o.gate_testvec(p)
+
+
+class LibBackend:
+    """The REAL library: every entry point goes to libtfhe_hip.so through the Python binding's ctypes layer (go-tfhe_amd/_binding.py), i.e.
+    the Go shim, executed by the interpreter, drives the GPU (-m gpu tier)."""
+
+    def __init__(self, pkg, oracle):
+        self.pkg, self.o = pkg, oracle
+
+    def device_count(self):
+        import ctypes
+        n = ctypes.c_int()
+        assert self.pkg.load_library().tfhe_device_count(ctypes.byref(n)) == 0
+        return n.value
+
+    def params(self, f):
+        return self.pkg.Params(**{k: int(f[k]) for k in ("n", "N", "Nbit", "L", "Bgbit", "basebit", "t")})
+
+    def _wrap(self, fn):
+        try:
+            return fn()
+        except self.pkg.TfheError as e:
+            raise MockError(getattr(e, "code", -1), str(e))
+
+    def create(self, p, device):
+        return self._wrap(lambda: self.pkg.Context(p, device))
+
+    def destroy(self, h):
+        h.close()
+
+    def clone(self, h, device):
+        c = self._wrap(lambda: h.clone_to(device))
+        return c, c.get_option("clone_path")
+
+    def load_bsk(self, h, p, arr):
+        self._wrap(lambda: h.load_bsk_fourier(arr))
+
+    def load_ksk(self, h, p, arr):
+        self._wrap(lambda: h.load_ksk(arr))
+
+    def gate_batch(self, h, p, codes, A, B, C):
+        return self._wrap(lambda: h.gate_batch(np.ascontiguousarray(codes, np.uint8), A, B, C))
+
+    def bootstrap_batch(self, h, p, X, T):
+        return self._wrap(lambda: h.bootstrap_batch(X, T))
+
+    def blind_rotate_batch(self, h, p, X, T, nsteps):
+        return self._wrap(lambda: h.blind_rotate_batch(X, T, int(nsteps)))
+
+    def gate_testvec(self, p):
+        return None                                         # NULL = the library's own gate test vector
+
+
 class MockC:
-    def __init__(self, interp, oracle, device_count=2):
-        self.I, self.o, self.ndev = interp, oracle, device_count
+    def __init__(self, interp, oracle=None, device_count=2, backend=None):
+        self.I = interp
+        self.be = backend or OracleBackend(oracle, device_count)
+        self.o, self.ndev = oracle, self.be.device_count()
         self.err = ""
         self.ctxs = []
         self.calls = []                      # (name, detail) log: the tests look at it (which device ran how many items)
@@ -80,14 +186,6 @@ class MockC:
             raise MockError(-1, "output buffer shorter than the ABI writes")
         ptr.a[ptr.i:ptr.i + flat.size] = [np.uint32(x) for x in flat.tolist()]
 
-    def oparams(self, f):
-        n, N, L, Bg, bb, t = (int(f[k]) for k in ("n", "N", "L", "Bgbit", "basebit", "t"))
-        for name in ("80", "110", "128", "uint5", "uint1", "uint3", "uint4", "uint2"):
-            p = self.o.params(name)
-            if (p.N, p.L, p.Bgbit, p.basebit, p.t) == (N, L, Bg, bb, t):
-                return p.small(n)
-        raise MockError(-1, f"unsupported parameter shape N={N} L={L} Bgbit={Bg}")
-
     # ---- the entry points the shim uses (include/tfhe_hip.h)
     def tfhe_last_error(self):
         return self.err
@@ -96,27 +194,32 @@ class MockC:
         gi.ptr_store(out, self.ndev)
         return 0
 
-    def tfhe_ctx_create(self, pptr, device, out):
-        p = self.oparams(gi.ptr_load(pptr).f)
-        if not 0 <= int(device) < self.ndev:
-            raise MockError(-1, f"device {device} not present ({self.ndev} visible)")
-        self.ctxs.append({"p": p, "device": int(device), "bsk": None, "ksk": None, "clone_path": 0})
+    def _new(self, rec, out):
+        self.ctxs.append(rec)
         gi.ptr_store(out, gi.GoPtr(gi.GoStruct(self.CTX, {"id": len(self.ctxs) - 1})))
+
+    def tfhe_ctx_create(self, pptr, device, out):
+        p = self.be.params(gi.ptr_load(pptr).f)
+        if isinstance(self.be, OracleBackend) and not 0 <= int(device) < self.ndev:
+            raise MockError(-1, f"device {device} not present ({self.ndev} visible)")
+        self._new({"p": p, "device": int(device), "h": self.be.create(p, int(device)), "clone_path": 0}, out)
         self.calls.append(("ctx_create", int(device)))
         return 0
 
     def tfhe_ctx_destroy(self, h):
         if h is not None:
-            self.ctx(h)
+            self.be.destroy(self.ctx(h)["h"])
             self.ctxs[int(h.v.f["id"])] = None
         return 0
 
     def tfhe_ctx_clone_to(self, h, device, out):
         src = self.ctx(h)
-        if not 0 <= int(device) < self.ndev:
+        if isinstance(self.be, OracleBackend) and not 0 <= int(device) < self.ndev:
             raise MockError(-1, f"device {device} not present ({self.ndev} visible)")
-        self.ctxs.append({"p": src["p"], "device": int(device), "bsk": src["bsk"], "ksk": src["ksk"], "clone_path": 1 if int(device) == src["device"] else 2})
-        gi.ptr_store(out, gi.GoPtr(gi.GoStruct(self.CTX, {"id": len(self.ctxs) - 1})))
+        hh, path = self.be.clone(src["h"], int(device))
+        if isinstance(self.be, OracleBackend):
+            path = 1 if int(device) == src["device"] else 2
+        self._new({"p": src["p"], "device": int(device), "h": hh, "clone_path": path}, out)
         self.calls.append(("clone_to", int(device)))
         return 0
 
@@ -130,25 +233,21 @@ class MockC:
     def tfhe_load_bsk_fourier(self, h, ptr):
         c = self.ctx(h)
         p = c["p"]
-        c["bsk"] = self.read(ptr, p.n * 2 * p.L * 2 * p.N, np.float64).reshape(p.n, 2 * p.L, 2, p.N)
+        self.be.load_bsk(c["h"], p, self.read(ptr, p.n * 2 * p.L * 2 * p.N, np.float64).reshape(p.n, 2 * p.L, 2, p.N))
         self.calls.append(("load_bsk", c["device"]))
         return 0
 
     def tfhe_load_ksk(self, h, ptr):
         c = self.ctx(h)
         p = c["p"]
-        c["ksk"] = self.read(ptr, p.ksk_rows * (p.n + 1), np.uint32).reshape(p.ksk_rows, p.n + 1)
+        rows = p.N * p.t * (1 << p.basebit)
+        self.be.load_ksk(c["h"], p, self.read(ptr, rows * (p.n + 1), np.uint32).reshape(rows, p.n + 1))
         self.calls.append(("load_ksk", c["device"]))
         return 0
 
-    def _keys(self, c, need_ksk=True):
-        if c["bsk"] is None or (need_ksk and c["ksk"] is None):
-            raise MockError(-2, "cloud key not loaded")
-        return c["p"], c["bsk"], c["ksk"]
-
     def tfhe_gate_batch(self, h, ops, op_uniform, a, b, cc, out, B):
         c = self.ctx(h)
-        p, bsk, ksk = self._keys(c)
+        p = c["p"]
         B, n1 = int(B), p.n + 1
         A, Bb = self.read(a, B * n1, np.uint32).reshape(B, n1), self.read(b, B * n1, np.uint32).reshape(B, n1)
         Cc = self.read(cc, B * n1, np.uint32).reshape(B, n1) if cc is not None else None
@@ -160,35 +259,32 @@ class MockC:
             codes = np.full(B, int(op_uniform), np.uint8)
         if (codes == 10).any() and Cc is None:
             raise MockError(-1, "MUX needs the third operand")
-        res, _ = self.o.gate_batch(p, bsk, ksk, codes, A, Bb, Cc)
-        self.write(out, res)
+        self.write(out, self.be.gate_batch(c["h"], p, codes, A, Bb, Cc))
         self.calls.append(("gate_batch", c["device"], B))
         return 0
 
     def tfhe_bootstrap_batch(self, h, inp, tv, per_item, out, B):
         c = self.ctx(h)
-        p, bsk, ksk = self._keys(c)
+        p = c["p"]
         B, n1 = int(B), p.n + 1
         X = self.read(inp, B * n1, np.uint32).reshape(B, n1)
         if tv is None:
-            T = self.o.gate_testvec(p)
+            T = self.be.gate_testvec(p)
         elif int(per_item):
             T = self.read(tv, B * 2 * p.N, np.uint32).reshape(B, 2, p.N)
         else:
             T = self.read(tv, 2 * p.N, np.uint32).reshape(2, p.N)
-        res, _ = self.o.bootstrap_batch(p, bsk, ksk, X, T)
-        self.write(out, res)
+        self.write(out, self.be.bootstrap_batch(c["h"], p, X, T))
         self.calls.append(("bootstrap_batch", c["device"], B))
         return 0
 
     def tfhe_blind_rotate_batch(self, h, inp, tv, per_item, out, B, nsteps):
         c = self.ctx(h)
-        p, bsk, _ = self._keys(c, need_ksk=False)
+        p = c["p"]
         B, n1 = int(B), p.n + 1
         X = self.read(inp, B * n1, np.uint32).reshape(B, n1)
-        T = self.o.gate_testvec(p) if tv is None else self.read(tv, 2 * p.N, np.uint32).reshape(2, p.N)
-        res = np.stack([self.o.blind_rotate(p, bsk, X[i], T, int(nsteps)) for i in range(B)])
-        self.write(out, res)
+        T = self.be.gate_testvec(p) if tv is None else self.read(tv, 2 * p.N, np.uint32).reshape(2, p.N)
+        self.write(out, self.be.blind_rotate_batch(c["h"], p, X, T, int(nsteps)))
         self.calls.append(("blind_rotate_batch", c["device"], B))
         return 0
 
