@@ -11,8 +11,8 @@ functions -- poly.Evaluator.ToFourierPolyAssign, Evaluator.ExternalProductAssign
 BootstrapAssign / BootstrapLUTAssign, trgsw.IdentityKeySwitchingAssign, gates.*, lut.Generator.GenLookUpTableAssign,
 cloudkey.NewCloudKey ... -- are executed from their source text, and their inputs and outputs become fixtures
 (tests/golden/goref/, written by tools/go_static/make_goref_vectors.py) that the oracle and the HIP engine are held to.
-It is NOT the Go toolchain: the executor is this file (400 statements per millisecond, so full-size keys are out of reach and
-the LWE dimension n is reduced for whole bootstraps), floating point is IEEE double exactly as Go on amd64 evaluates it (no
+It is NOT the Go toolchain: the executor is this file (~10^5 Go statements per second: a full-size bootstrap is ~25 minutes, so only a
+handful are run at n = 700 and the reference's own key generation is run at a reduced LWE dimension), floating point is IEEE double exactly as Go on amd64 evaluates it (no
 fused multiply-add), and math/cmplx functions come from the C library (twiddles within 1 ulp of Go's pure-Go versions:
 immaterial where the transforms are exact, inside the stated tolerance elsewhere).
 
