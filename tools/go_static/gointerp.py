@@ -422,9 +422,9 @@ class Interp:
                     return NP[n](m)
                 raise Unsupported(f"convert {type(v).__name__} to {n}")
             if n in PYINT:
-                if isinstance(v, float):
-                    r = int(math.trunc(v))
-                elif isinstance(v, np.floating):
+                if isinstance(v, (float, np.floating)):
+                    if not -9.3e18 < float(v) < 1.9e19:       # Go: the result of an out-of-range float -> integer conversion is implementation-defined
+                        raise Unsupported(f"float {v} is outside the range of {n}")
                     r = int(math.trunc(float(v)))
                 else:
                     r = int(v)
@@ -1279,17 +1279,20 @@ class Interp:
                 if sh >= 8 * a.itemsize:
                     return type(a)(0) if op == "<<" or a >= 0 else type(a)(-1)
                 return type(a)(a << type(a)(sh)) if op == "<<" else type(a)(a >> type(a)(sh))
-            return a << sh if op == "<<" else a >> sh
+            r = a << sh if op == "<<" else a >> sh
+            if type(r) is int and not -9223372036854775808 <= r <= 18446744073709551615:
+                raise Unsupported(f"64-bit integer overflow in {a} << {sh}: Go would wrap here, the interpreter does not model it")
+            return r
         if an and not bn and isinstance(b, int) and not isinstance(b, bool) and isinstance(a, np.integer):
             b = self.convert(BASIC_RT[a.dtype.name], b)
         elif bn and not an and isinstance(a, int) and not isinstance(a, bool) and isinstance(b, np.integer):
             a = self.convert(BASIC_RT[b.dtype.name], a)
-        if op == "+":
-            return a + b
-        if op == "-":
-            return a - b
-        if op == "*":
-            return a * b
+        if op in ("+", "-", "*"):
+            r = a + b if op == "+" else a - b if op == "-" else a * b
+            # Go's int / int64 / uint64 are Python ints here: a result outside 64 bits would WRAP in Go and not here -- never silently
+            if type(r) is int and not -9223372036854775808 <= r <= 18446744073709551615:
+                raise Unsupported(f"64-bit integer overflow in {a} {op} {b}: Go would wrap here, the interpreter does not model it")
+            return r
         if op == "/":
             if isinstance(a, (float, complex)) or isinstance(b, (float, complex)) or isinstance(a, np.floating):
                 return a / b
