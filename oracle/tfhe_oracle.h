@@ -5,10 +5,15 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  * The product path (go-tfhe_amd/) never links, imports or falls back to it.
  *
- * PARITY PIN STATUS: "parity unpinned" at the ciphertext-sample level.
- * The reference (pure Go, no Go toolchain in this image) cannot be built or run
- * here, and its own tests hold no golden ciphertexts / seeded RNG for this path
- * (SURVEY.md section 4, 8c).  What the reference's tests DO pin is checked in
+ * PARITY PIN STATUS.  The reference is pure Go and this image has no Go toolchain: it
+ * cannot be BUILT here, and its own tests hold no golden ciphertexts / seeded RNG for
+ * this path -- against a Go binary, parity is "unpinned".
+ * Since round 5 the reference's SOURCE TEXT is executed here instead, by the Go-subset
+ * interpreter tools/go_static/gointerp.py (on which 54 of the reference's own unit
+ * tests pass), and this restatement is held bit for bit to what the reference's
+ * functions computed -- up to whole bootstraps and every gate at the full 80-, 110-
+ * and 128-bit sets and Uint5 programmable bootstraps (tests/golden/goref/,
+ * tests/test_goref_vectors.py).  What the reference's tests DO pin is also checked in
  * tests/test_oracle_*.py: the F64ToTorus known answers (utils/utils_test.go:15-20),
  * the FFT round trip bound (poly/poly_test.go:10-33), the gate truth tables
  * (gates/gates_test.go:23-366) and the PBS identity/complement/modulo cases

@@ -331,6 +331,34 @@ def test_gpu_full_size_bootstraps_and_gates_equal_the_reference_source(pkg, keys
         pytest.skip("no full-size vectors (make_goref_vectors.py --jobs full)")
 
 
+def _keys110(oracle):
+    p = oracle.params("110")
+    rng = oracle.rng(0x7F4E0110)
+    s0, s1 = oracle.keygen_secret(p, rng)
+    _, bsk_f = oracle.keygen_bsk(p, rng, s0, s1, torus=True, fourier=True)
+    return p, s0, bsk_f, oracle.keygen_ksk(p, rng, s0, s1)
+
+
+def test_oracle_full_size_110bit_xor_equals_the_reference_source(oracle):
+    f = load("full110_gate_XOR")                            # the third gate set of params.go, n = 630
+    p, s0, bsk_f, ksk = _keys110(oracle)
+    got = oracle.gate(p, bsk_f, ksk, "XOR", f["a"], f["b"])
+    assert np.array_equal(got, f["out"])
+    assert bool(oracle.decrypt_bools(p, s0, got[None])[0]) == (bool(f["bits"][0]) != bool(f["bits"][1]))
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_110bit_xor_equals_the_reference_source(pkg, oracle):
+    from conftest import gpu_params
+    f = load("full110_gate_XOR")
+    p, s0, bsk_f, ksk = _keys110(oracle)
+    ck = pkg.CloudKey(gpu_params(pkg, p), bsk_fourier=bsk_f, ksk=ksk)
+    try:
+        assert np.array_equal(ck.ctx.gate_batch("XOR", f["a"][None], f["b"][None])[0], f["out"])
+    finally:
+        ck.close()
+
+
 @pytest.mark.gpu
 def test_gpu_full_size_80bit_nand_equals_the_reference_source(pkg, keys80, ck80):
     f = load("full80_gate_NAND")                            # BASELINE configs[0] on the engine

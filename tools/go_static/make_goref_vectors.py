@@ -515,6 +515,22 @@ def job_full(spec):
         save(f"full80_gate_{arg}", a=a[0], b=b[0], bits=bits[:, 0].astype(np.uint8), out=R.u32(r.v.f["P"]),
              meta=R.meta(f"gates.{arg} at the FULL 80-bit set (n = 550, N = 1024: BASELINE configs[0]) with keys80 (tests/conftest.py, seed 0x7F4E0001); inputs from the "
                          "oracle harness, seed 0x7F4E00C9"))
+    elif kind == "gate110":
+        # the third gate set of params.go (110-bit, "original TFHE reference parameters": n = 630), one gate at full size
+        o = oracle()
+        p = o.params("110")
+        rng = o.rng(0x7F4E0110)
+        s0, s1 = o.keygen_secret(p, rng)
+        _, bsk_f = o.keygen_bsk(p, rng, s0, s1, torus=True, fourier=True)
+        ksk = o.keygen_ksk(p, rng, s0, s1)
+        erng = o.rng(0x7F4E00CB)
+        bits = np.array([[1], [0]])
+        a, b = (o.encrypt_bools(p, erng, bits[k], s0) for k in range(2))
+        R = Ref("110")
+        ck = R.cloudkey(bsk_f, ksk)
+        r = R.I.call_func("gates", arg, R.lwe(a[0]), R.lwe(b[0]), ck)
+        save(f"full110_gate_{arg}", a=a[0], b=b[0], bits=bits[:, 0].astype(np.uint8), out=R.u32(r.v.f["P"]), key_seed=np.int64(0x7F4E0110),
+             meta=R.meta(f"gates.{arg} at the FULL 110-bit set (n = 630, N = 1024) with a key from the oracle harness (seed 0x7F4E0110); inputs seed 0x7F4E00CB"))
     elif kind == "ingest":
         # the reference's key ingest over a whole slice of the full key: trgsw.NewTRGSWLv1FFT(bsk_torus[i]) == the oracle's Fourier key, bit for bit
         o, p, rng, s0, s1, bsk_t, bsk_f, ksk = full_key_128()
@@ -562,7 +578,7 @@ SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chai
          "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
          "go_golden_program": job_go_golden_program}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
-       [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND")]
+       [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")]
 
 
 def run_small(name):
