@@ -48,7 +48,7 @@ func checkOffset(decompositionOffset params.Torus) {
 	}
 }
 
-// BlindRotateAssign performs blind rotation and writes to ctOut (evaluator/evaluator.go:110).
+// BlindRotateAssign: the accumulator after all n CMUX steps, into ctOut.  Reference: evaluator/evaluator.go:110.
 func (e *Evaluator) BlindRotateAssign(ctIn *tlwe.TLWELv0, testvec *trlwe.TRLWELv1, bsk []*trgsw.TRGSWLv1FFT, decompositionOffset params.Torus, ctOut *trlwe.TRLWELv1) {
 	checkOffset(decompositionOffset)
 	res := gpu.Attached(bsk, nil).Pick().BlindRotateBatch([]*tlwe.TLWELv0{ctIn}, testvec)
@@ -56,15 +56,15 @@ func (e *Evaluator) BlindRotateAssign(ctIn *tlwe.TLWELv0, testvec *trlwe.TRLWELv
 	copy(ctOut.B, res[0].B)
 }
 
-// BootstrapAssign performs full bootstrapping, blind rotate + sample extract + key switch, into ctOut
-// (evaluator/evaluator.go:139).
+// BootstrapAssign: blind rotation, sample extraction and key switch in one call of the engine, into ctOut.
+// Reference: evaluator/evaluator.go:139.
 func (e *Evaluator) BootstrapAssign(ctIn *tlwe.TLWELv0, testvec *trlwe.TRLWELv1, bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0, decompositionOffset params.Torus, ctOut *tlwe.TLWELv0) {
 	checkOffset(decompositionOffset)
 	res := gpu.Attached(bsk, ksk).Pick().BootstrapBatch([]*tlwe.TLWELv0{ctIn}, testvec)
 	copy(ctOut.P, res[0].P)
 }
 
-// Bootstrap performs full bootstrapping and returns the result (evaluator/evaluator.go:152).  The reference returns a
+// Bootstrap returns a fresh sample.  Reference: evaluator/evaluator.go:152, which returns a
 // pointer into a four-slot ring that is valid "until 4 more bootstrap calls"; this result owns its storage.
 func (e *Evaluator) Bootstrap(ctIn *tlwe.TLWELv0, testvec *trlwe.TRLWELv1, bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0, decompositionOffset params.Torus) *tlwe.TLWELv0 {
 	result := tlwe.NewTLWELv0()
@@ -72,13 +72,13 @@ func (e *Evaluator) Bootstrap(ctIn *tlwe.TLWELv0, testvec *trlwe.TRLWELv1, bsk [
 	return result
 }
 
-// BootstrapLUTAssign performs programmable bootstrapping with a lookup table (evaluator/programmable_bootstrap.go:93):
-// the table's polynomial is the test vector.
+// BootstrapLUTAssign: the table's polynomial is the test vector of an ordinary bootstrap.
+// Reference: evaluator/programmable_bootstrap.go:93.
 func (e *Evaluator) BootstrapLUTAssign(ctIn *tlwe.TLWELv0, lut *lut.LookUpTable, bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0, decompositionOffset params.Torus, ctOut *tlwe.TLWELv0) {
 	e.BootstrapAssign(ctIn, lut.Poly, bsk, ksk, decompositionOffset, ctOut)
 }
 
-// BootstrapLUT performs programmable bootstrapping with a pre-computed lookup table (evaluator/programmable_bootstrap.go:54).
+// BootstrapLUT.  Reference: evaluator/programmable_bootstrap.go:54.
 func (e *Evaluator) BootstrapLUT(ctIn *tlwe.TLWELv0, lut *lut.LookUpTable, bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0, decompositionOffset params.Torus) *tlwe.TLWELv0 {
 	result := tlwe.NewTLWELv0()
 	e.BootstrapLUTAssign(ctIn, lut, bsk, ksk, decompositionOffset, result)
@@ -90,8 +90,8 @@ func (e *Evaluator) BootstrapLUTTemp(ctIn *tlwe.TLWELv0, lut *lut.LookUpTable, b
 	return e.BootstrapLUT(ctIn, lut, bsk, ksk, decompositionOffset)
 }
 
-// BootstrapFunc performs programmable bootstrapping with a function on [0, messageModulus)
-// (evaluator/programmable_bootstrap.go:16).
+// BootstrapFunc builds the table of f over [0, messageModulus) on the host and bootstraps through it.
+// Reference: evaluator/programmable_bootstrap.go:16.
 func (e *Evaluator) BootstrapFunc(ctIn *tlwe.TLWELv0, f func(int) int, messageModulus int, bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0, decompositionOffset params.Torus) *tlwe.TLWELv0 {
 	generator := lut.NewGenerator(messageModulus)
 	lookupTable := generator.GenLookUpTable(f)
@@ -112,46 +112,34 @@ func (e *Evaluator) BatchBootstrapLUT(ctsIn []*tlwe.TLWELv0, lut *lut.LookUpTabl
 	return gpu.Attached(bsk, ksk).BootstrapBatch(ctsIn, lut.Poly)
 }
 
-// PrepareNAND prepares a NAND input for bootstrapping: -(a + b) + 1/8 (evaluator/gates_helper.go:10).
+// combine is the linear step in front of a gate bootstrap: ca*a + cb*b on every word, with mu added to the body
+// (evaluator/gates_helper.go:10-63 writes it out per gate; -x is (2^32 - 1)*x on the torus).
+func combine(a, b *tlwe.TLWELv0, ca, cb params.Torus, mu float64) *tlwe.TLWELv0 {
+	out := tlwe.NewTLWELv0()
+	for i := range out.P {
+		out.P[i] = ca*a.P[i] + cb*b.P[i]
+	}
+	out.SetB(out.B() + utils.F64ToTorus(mu))
+	return out
+}
+
+// PrepareNAND: -(a + b) + 1/8.  Reference: evaluator/gates_helper.go:10.
 func (e *Evaluator) PrepareNAND(a, b *tlwe.TLWELv0) *tlwe.TLWELv0 {
-	n := params.GetTLWELv0().N
-	result := tlwe.NewTLWELv0()
-	for i := 0; i < n; i++ {
-		result.P[i] = -(a.P[i] + b.P[i])
-	}
-	result.P[n] = -(a.P[n] + b.P[n]) + utils.F64ToTorus(0.125)
-	return result
+	minusOne := ^params.Torus(0)
+	return combine(a, b, minusOne, minusOne, 0.125)
 }
 
-// PrepareAND prepares an AND input for bootstrapping: (a + b) - 1/8 (evaluator/gates_helper.go:24).
+// PrepareAND: (a + b) - 1/8.  Reference: evaluator/gates_helper.go:24.
 func (e *Evaluator) PrepareAND(a, b *tlwe.TLWELv0) *tlwe.TLWELv0 {
-	n := params.GetTLWELv0().N
-	result := tlwe.NewTLWELv0()
-	for i := 0; i < n; i++ {
-		result.P[i] = a.P[i] + b.P[i]
-	}
-	result.P[n] = a.P[n] + b.P[n] + utils.F64ToTorus(-0.125)
-	return result
+	return combine(a, b, 1, 1, -0.125)
 }
 
-// PrepareOR prepares an OR input for bootstrapping: (a + b) + 1/8 (evaluator/gates_helper.go:38).
+// PrepareOR: (a + b) + 1/8.  Reference: evaluator/gates_helper.go:38.
 func (e *Evaluator) PrepareOR(a, b *tlwe.TLWELv0) *tlwe.TLWELv0 {
-	n := params.GetTLWELv0().N
-	result := tlwe.NewTLWELv0()
-	for i := 0; i < n; i++ {
-		result.P[i] = a.P[i] + b.P[i]
-	}
-	result.P[n] = a.P[n] + b.P[n] + utils.F64ToTorus(0.125)
-	return result
+	return combine(a, b, 1, 1, 0.125)
 }
 
-// PrepareXOR prepares an XOR input for bootstrapping: (a + 2b) + 1/4 (evaluator/gates_helper.go:52).
+// PrepareXOR: (a + 2b) + 1/4.  Reference: evaluator/gates_helper.go:52.
 func (e *Evaluator) PrepareXOR(a, b *tlwe.TLWELv0) *tlwe.TLWELv0 {
-	n := params.GetTLWELv0().N
-	result := tlwe.NewTLWELv0()
-	for i := 0; i < n; i++ {
-		result.P[i] = a.P[i] + 2*b.P[i]
-	}
-	result.P[n] = a.P[n] + 2*b.P[n] + utils.F64ToTorus(0.25)
-	return result
+	return combine(a, b, 1, 2, 0.25)
 }

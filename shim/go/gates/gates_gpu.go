@@ -12,11 +12,12 @@ package gates
 import (
 	"github.com/thedonutfactory/go-tfhe-gpu/gpu"
 	"github.com/thedonutfactory/go-tfhe/cloudkey"
+	"github.com/thedonutfactory/go-tfhe/params"
 	"github.com/thedonutfactory/go-tfhe/tlwe"
 	"github.com/thedonutfactory/go-tfhe/utils"
 )
 
-// Ciphertext is an alias for TLWELv0 (gates/gates.go:16).
+// Ciphertext: the same alias the reference declares (gates/gates.go:16).
 type Ciphertext = tlwe.TLWELv0
 
 func keys(ck *cloudkey.CloudKey) *gpu.CloudKeySet {
@@ -43,63 +44,64 @@ func batch(op int, inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext
 	return keys(ck).GateBatch(op, a, b, nil)
 }
 
-// NAND performs homomorphic NAND operation (gates/gates.go:26).
+// NAND: NOT(a AND b).  Reference: gates/gates.go:26.
 func NAND(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpNAND, tlweA, tlweB, ck)
 }
 
-// OR performs homomorphic OR operation (gates/gates.go:34).
+// OR.  Reference: gates/gates.go:34.
 func OR(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpOR, tlweA, tlweB, ck)
 }
 
-// AND performs homomorphic AND operation (gates/gates.go:40).
+// AND.  Reference: gates/gates.go:40.
 func AND(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpAND, tlweA, tlweB, ck)
 }
 
-// XOR performs homomorphic XOR operation (gates/gates.go:46).
+// XOR.  Reference: gates/gates.go:46.
 func XOR(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpXOR, tlweA, tlweB, ck)
 }
 
-// XNOR performs homomorphic XNOR operation (gates/gates.go:52).
+// XNOR, with the +1/4 of the reference's scalar gate.  Reference: gates/gates.go:52.
 func XNOR(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpXNOR, tlweA, tlweB, ck)
 }
 
-// Constant creates a constant encrypted value (gates/gates.go:61; host only, no key involved).
+// Constant is a trivial (noiseless, keyless) encryption of `value`: host code only.  Reference: gates/gates.go:61.
 func Constant(value bool) *Ciphertext {
-	mu := utils.F64ToTorus(0.125)
-	if !value {
-		mu = 1 - mu
+	out := tlwe.NewTLWELv0()
+	eighth := utils.F64ToTorus(0.125)
+	if value {
+		out.SetB(eighth)
+	} else {
+		out.SetB(1 - eighth) // the reference's encoding of false: 1 - mu, not -mu (gates/gates.go:63-65)
 	}
-	result := tlwe.NewTLWELv0()
-	result.SetB(mu)
-	return result
+	return out
 }
 
-// NOR performs homomorphic NOR operation (gates/gates.go:72).
+// NOR.  Reference: gates/gates.go:72.
 func NOR(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpNOR, tlweA, tlweB, ck)
 }
 
-// ANDNY performs homomorphic AND-NOT-Y operation: NOT(a) AND b (gates/gates.go:79).
+// ANDNY: (NOT a) AND b.  Reference: gates/gates.go:79.
 func ANDNY(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpANDNY, tlweA, tlweB, ck)
 }
 
-// ANDYN performs homomorphic AND-Y-NOT operation: a AND NOT(b) (gates/gates.go:86).
+// ANDYN: a AND (NOT b).  Reference: gates/gates.go:86.
 func ANDYN(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpANDYN, tlweA, tlweB, ck)
 }
 
-// ORNY performs homomorphic OR-NOT-Y operation: NOT(a) OR b (gates/gates.go:93).
+// ORNY: (NOT a) OR b.  Reference: gates/gates.go:93.
 func ORNY(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpORNY, tlweA, tlweB, ck)
 }
 
-// ORYN performs homomorphic OR-Y-NOT operation: a OR NOT(b) (gates/gates.go:100).
+// ORYN: a OR (NOT b).  Reference: gates/gates.go:100.
 func ORYN(tlweA, tlweB *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return gate(gpu.OpORYN, tlweA, tlweB, ck)
 }
@@ -111,44 +113,42 @@ func MUX(tlweA, tlweB, tlweC *Ciphertext, ck *cloudkey.CloudKey) *Ciphertext {
 	return out[0]
 }
 
-// NOT performs homomorphic NOT operation (gates/gates.go:117; no bootstrap).
+// NOT negates the sample; no bootstrap, no key.  Reference: gates/gates.go:117.
 func NOT(tlweA *Ciphertext) *Ciphertext {
 	return tlweA.Neg()
 }
 
-// Copy copies a ciphertext (gates/gates.go:122).
+// Copy returns a sample that owns a copy of the words.  Reference: gates/gates.go:122.
 func Copy(tlweA *Ciphertext) *Ciphertext {
-	result := tlwe.NewTLWELv0()
-	copy(result.P, tlweA.P)
-	return result
+	return &tlwe.TLWELv0{P: append([]params.Torus(nil), tlweA.P...)}
 }
 
-// BatchNAND performs batch NAND operations in parallel (gates/gates.go:156).
+// BatchNAND: NAND over [][2]*Ciphertext, sharded over every GPU.  Reference: gates/gates.go:156.
 func BatchNAND(inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext {
 	return batch(gpu.OpNAND, inputs, ck)
 }
 
-// BatchAND performs batch AND operations in parallel (gates/gates.go:185).
+// BatchAND.  Reference: gates/gates.go:185.
 func BatchAND(inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext {
 	return batch(gpu.OpAND, inputs, ck)
 }
 
-// BatchOR performs batch OR operations in parallel (gates/gates.go:211).
+// BatchOR.  Reference: gates/gates.go:211.
 func BatchOR(inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext {
 	return batch(gpu.OpOR, inputs, ck)
 }
 
-// BatchXOR performs batch XOR operations in parallel (gates/gates.go:237).
+// BatchXOR.  Reference: gates/gates.go:237.
 func BatchXOR(inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext {
 	return batch(gpu.OpXOR, inputs, ck)
 }
 
-// BatchNOR performs batch NOR operations in parallel (gates/gates.go:263).
+// BatchNOR.  Reference: gates/gates.go:263.
 func BatchNOR(inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext {
 	return batch(gpu.OpNOR, inputs, ck)
 }
 
-// BatchXNOR performs batch XNOR operations in parallel (gates/gates.go:289) -- with the scalar XNOR's +1/4.
+// BatchXNOR, with the scalar XNOR's +1/4 (the reference's batch form adds -1/4 and computes XOR).  Reference: gates/gates.go:289.
 func BatchXNOR(inputs [][2]*Ciphertext, ck *cloudkey.CloudKey) []*Ciphertext {
 	return batch(gpu.OpXNOR, inputs, ck)
 }

@@ -147,7 +147,7 @@ MUTATIONS = [
     ("shim/go/gpu/gpu.go", "sk.KeyLv0), torusPtr(sk.KeyLv1)", "sk.KeyLv0), torusPtr(sk.KeyLvl1)", "has no field or method KeyLvl1"),
     ("shim/go/gates/gates_gpu.go", "return gpu.Attached(ck.BootstrappingKey, ck.KeySwitchingKey)", "return gpu.Attached(ck.KeySwitchingKey, ck.BootstrappingKey)", "cannot use"),
     ("shim/go/gates/gates_gpu.go", "return gate(gpu.OpNAND, tlweA, tlweB, ck)", "return gate(gpu.OpNANDS, tlweA, tlweB, ck)", "undefined: gpu.OpNANDS"),
-    ("shim/go/gates/gates_gpu.go", "\tresult.SetB(mu)\n", "\tresult.SetB(0.125)\n", "cannot use untyped float"),
+    ("shim/go/gates/gates_gpu.go", "\t\tout.SetB(eighth)\n", "\t\tout.SetB(0.125)\n", "cannot use untyped float"),
     ("shim/go/evaluator/evaluator_gpu.go", "e.BootstrapAssign(ctIn, lut.Poly, bsk, ksk, decompositionOffset, ctOut)", "e.BootstrapAssign(ctIn, lut, bsk, ksk, decompositionOffset, ctOut)", "cannot use"),
     ("shim/go/evaluator/evaluator_gpu.go", "copy(ctOut.P, res[0].P)", "copy(ctOut.P, res[0].A)", "has no field or method A"),
     ("shim/go/evaluator/evaluator_gpu.go", "lookupTable := generator.GenLookUpTable(f)\n\treturn", "lookupTable := generator.GenLookupTable(f)\n\treturn", "has no field or method GenLookupTable"),
