@@ -429,7 +429,7 @@ class Context:
                                                   blob.numel() * blob.element_size(), self._stream(stream)))
 
     OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4, "combine_max": 5, "combine_launches": 6,
-               "combine_requests": 7, "ks_wide_ct": 8, "clone_path": 9}
+               "combine_requests": 7, "ks_wide_ct": 8, "clone_path": 9, "clone_force_host": 10}
     CLONE_PATHS = {0: "not a clone", 1: "same device (D2D)", 2: "peer copy (xGMI)", 3: "host-staged (no peer access)"}
 
     def set_option(self, name, value):

@@ -158,6 +158,7 @@ struct tfhe_ctx {
     void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
                                                         // reads them after the call has returned
     int clone_path = 0;                                 // TFHE_OPT_CLONE_PATH: how tfhe_ctx_clone_to brought the keys here (0 = not a clone)
+    bool clone_force_host = false;                      // TFHE_OPT_CLONE_FORCE_HOST (tests): clones OF this context take the host-staged path
     bool need_sync_all = false;                         // a stream's event could not be recorded: tfhe_ctx_sync falls back to hipDeviceSynchronize
 };
 
@@ -1238,6 +1239,7 @@ int tfhe_ctx_set_option(tfhe_ctx *c, int option, int value)
         return TFHE_OK;
     case TFHE_OPT_FROZEN: c->frozen = value != 0; return TFHE_OK;
     case TFHE_OPT_COMBINE_MAX: c->combine_max = value < 0 ? launch_items(c) : value; return TFHE_OK;
+    case TFHE_OPT_CLONE_FORCE_HOST: c->clone_force_host = value != 0; return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT:
         if (value > 0 && value != 64 && value != 128) return fail(TFHE_E_INVALID, "TFHE_OPT_KS_WIDE_CT is 64, 128 or 0 / -1 (by batch size)");
         c->ks_wide_ct = value < 0 ? 0 : value;
@@ -1258,6 +1260,7 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_COMBINE_MAX: *value = c->combine_max.load(); return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT: *value = c->ks_wide_ct; return TFHE_OK;
     case TFHE_OPT_CLONE_PATH: *value = c->clone_path; return TFHE_OK;
+    case TFHE_OPT_CLONE_FORCE_HOST: *value = c->clone_force_host ? 1 : 0; return TFHE_OK;
     // the counters are 64-bit; the option interface is int: saturate instead of wrapping
     case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)std::min<long long>(c->comb_launches.load(), INT_MAX); return TFHE_OK;
     case TFHE_OPT_COMBINE_REQUESTS: *value = (int)std::min<long long>(c->comb_requests.load(), INT_MAX); return TFHE_OK;
@@ -1582,7 +1585,7 @@ constexpr size_t kCloneStage = (size_t)32 << 20;
 
 int peer_copy(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, bool peers, hipStream_t st, void *bounce)
 {
-    if (dst_dev == src_dev) {
+    if (dst_dev == src_dev && !bounce) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
         return TFHE_OK;
     }
@@ -1617,7 +1620,9 @@ int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out)
     bool peers = false;
     void *bounce = nullptr;
     struct Bounce { void *&p; ~Bounce() { if (p) (void)hipHostFree(p); } } bounce_guard{bounce};
-    if (device_id != src->device) {
+    if (src->clone_force_host) {                                  // tests: the fallback of devices that are not peers, on any box
+        HIP_TRY(hipHostMalloc(&bounce, kCloneStage, hipHostMallocDefault));
+    } else if (device_id != src->device) {
         int can = 0;
         HIP_TRY(hipDeviceCanAccessPeer(&can, device_id, src->device));
         if (can) {
@@ -1628,7 +1633,7 @@ int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out)
         }
         if (!peers) HIP_TRY(hipHostMalloc(&bounce, kCloneStage, hipHostMallocDefault));
     }
-    dst->clone_path = device_id == src->device ? 1 : peers ? 2 : 3;
+    dst->clone_path = bounce ? 3 : device_id == src->device ? 1 : 2;
     hipStream_t st = dst->stream;
     if (src->have_bsk) {
         const size_t bytes = key_payload_bytes(src, 0);

@@ -122,6 +122,8 @@ enum {
     TFHE_OPT_COMBINE_REQUESTS = 7,  /* ... and the tfhe_gate_batch calls they carried                                       */
     TFHE_OPT_KS_WIDE_CT = 8,   /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
                                   only: one wave per SIMD, slower)                                                         */
+    TFHE_OPT_CLONE_FORCE_HOST = 10, /* tests: 1 = clones OF this context take the host-staged path (the fallback of devices that are
+                                  not peers) whatever the devices are, so that the path is exercised on a one-GPU box          */
     TFHE_OPT_CLONE_PATH = 9    /* read-only: how tfhe_ctx_clone_to brought this context's keys here: 0 = not a clone, 1 = same
                                   GPU (device-to-device copy), 2 = peer copy GPU to GPU (xGMI), 3 = staged through page-locked
                                   host memory (the devices are not peers)                                                  */

@@ -82,3 +82,24 @@ def test_cloud_key_set_shards_a_ragged_batch_in_order(pkg, keys_small, ck_small)
         assert np.array_equal(ks.gate_batch("XNOR", a[:2], b[:2]), ck_small.ctx.gate_batch("XNOR", a[:2], b[:2]))   # fewer items than replicas
     finally:
         ks.close()
+
+
+def test_host_staged_fallback_path_gives_the_same_replica(pkg, keys_small, ck_small):
+    # the documented fallback of tfhe_ctx_clone_to when the two devices are not peers (copy staged through 32 MB of page-locked host
+    # memory), forced here on the one GPU of the box: same blobs, same outputs, clone path 3
+    k = keys_small
+    ck_small.ctx.set_option("clone_force_host", 1)
+    try:
+        rep = ck_small.clone_to(0)
+    finally:
+        ck_small.ctx.set_option("clone_force_host", 0)
+    try:
+        assert rep.ctx.get_option("clone_path") == 3
+        for which in (0, 1):
+            assert torch.equal(rep.ctx.key_export_dev(which).cpu(), ck_small.ctx.key_export_dev(which).cpu())
+        rs = np.random.RandomState(13)
+        a, b = rand_u32(rs, (9, k.p.n + 1)), rand_u32(rs, (9, k.p.n + 1))
+        assert np.array_equal(rep.ctx.gate_batch("XOR", a, b), ck_small.ctx.gate_batch("XOR", a, b))
+    finally:
+        rep.close()
+    assert ck_small.clone_to(0).ctx.get_option("clone_path") == 1          # back to the device-to-device path
