@@ -109,3 +109,46 @@ def test_a_library_error_reaches_go_as_a_panic(world):
     w = world
     with pytest.raises(w["gi"].GoPanic, match="tfhe_hip: .*not present"):
         w["call"]("gpu", "UploadKeys", w["ck"].v.f["BootstrappingKey"], w["ck"].v.f["KeySwitchingKey"], 4096)
+
+
+@pytest.mark.gpu
+def test_the_shims_keygen_save_and_load_on_the_gpu(pkg, oracle, keys_small):
+    """gpu.NewCloudKey (cloudkey.NewCloudKey replaced by GPU key generation from the secret key), CloudKey.Save / Load (the engine's key
+    blobs) through the shim, executed by the interpreter against the real library: a GPU-generated key bootstraps correctly, and a
+    context loaded from the saved blobs returns the same words."""
+    import cmock
+    import gointerp as gi
+    k = keys_small
+    I = gi.Interp(os.path.join(ROOT, "tests", "go_stubs"))
+    I.extra_roots = {MOD: os.path.join(ROOT, "shim", "go")}
+    P = I.load("params")
+    I.pkg_value(P, "Lv0").f["N"] = int(k.p.n)
+    mock = cmock.MockC(I, oracle, backend=cmock.LibBackend(pkg, oracle))
+    TORUS = I.named(P, "Torus")
+    torus = lambda a: gi.np_to_slice(np.ascontiguousarray(a, np.uint32), TORUS, np.uint32)                      # noqa: E731
+    sk = gi.GoPtr(gi.GoStruct(I.named(I.load("key"), "SecretKey"), {"KeyLv0": torus(k.s0), "KeyLv1": torus(k.s1)}))
+    gpu = I.pkg_by_import(f"{MOD}/gpu")
+    call = lambda fn, *a: I.call_decl(gpu.funcs[fn], gpu, list(a), None)                                        # noqa: E731
+    lwe = lambda row: gi.GoPtr(gi.GoStruct(I.named(I.load("tlwe"), "TLWELv0"), {"P": torus(row)}))              # noqa: E731
+    key = call("NewCloudKey", sk, 0)
+    bits_a, bits_b = [0, 0, 1, 1], [0, 1, 0, 1]
+    a, b = k.enc(bits_a), k.enc(bits_b)
+    sa = gi.GoSlice([lwe(r) for r in a], 0, 4, 4, None)
+    sb = gi.GoSlice([lwe(r) for r in b], 0, 4, 4, None)
+    nand = int(I.pkg_value(gpu, "OpNAND"))
+    res = I.call_method(key, "GateBatch", nand, sa, sb, None)
+    got = np.stack([gi.slice_to_np(res.a[i].v.f["P"], np.uint32) for i in range(4)])
+    assert np.array_equal(k.dec(got), ~(np.array(bits_a, bool) & np.array(bits_b, bool)))          # a GPU-generated key works
+    blobs = [I.call_method(key, "Save", w) for w in (0, 1)]
+    assert [b_.n for b_ in blobs] == [mock.be.key_size(mock.ctxs[0]["h"], w) for w in (0, 1)]
+    other = call("newContext", 0)
+    for w in (0, 1):
+        I.call_method(other, "Load", w, blobs[w])
+    res2 = I.call_method(other, "GateBatch", nand, sa, sb, None)
+    got2 = np.stack([gi.slice_to_np(res2.a[i].v.f["P"], np.uint32) for i in range(4)])
+    assert np.array_equal(got2, got)                                                               # same key, same words
+    with pytest.raises(gi.GoPanic, match="tfhe_hip: "):                                            # the other key's blob is refused, as a panic
+        I.call_method(other, "Load", 0, blobs[1])
+    I.call_method(key, "Close")
+    I.call_method(other, "Close")
+    assert [c[0] for c in mock.calls].count("keygen") == 1

@@ -118,6 +118,18 @@ class LibBackend:
     def gate_testvec(self, p):
         return None                                         # NULL = the library's own gate test vector
 
+    def keygen(self, h, p, s0, s1, a0, a1):
+        self._wrap(lambda: h.keygen_cloud(s0, s1, a0, a1, None))
+
+    def key_size(self, h, which):
+        return self._wrap(lambda: h.key_size(which))
+
+    def key_export(self, h, which):
+        return self._wrap(lambda: h.key_export(which))
+
+    def key_import(self, h, which, blob):
+        self._wrap(lambda: h.key_import(which, blob))
+
 
 class MockC:
     def __init__(self, interp, oracle=None, device_count=2, backend=None):
@@ -243,6 +255,32 @@ class MockC:
         rows = p.N * p.t * (1 << p.basebit)
         self.be.load_ksk(c["h"], p, self.read(ptr, rows * (p.n + 1), np.uint32).reshape(rows, p.n + 1))
         self.calls.append(("load_ksk", c["device"]))
+        return 0
+
+    def tfhe_keygen_cloud_seeded(self, h, s0, s1, a0, a1, seed):
+        c = self.ctx(h)
+        p = c["p"]
+        if seed is not None:
+            raise MockError(-1, "the shim passes a nil seed (OS entropy)")
+        self.be.keygen(c["h"], p, self.read(s0, p.n, np.uint32), self.read(s1, p.N, np.uint32), float(a0), float(a1))
+        self.calls.append(("keygen", c["device"]))
+        return 0
+
+    def tfhe_key_size(self, h, which, out):
+        gi.ptr_store(out, int(self.be.key_size(self.ctx(h)["h"], int(which))))
+        return 0
+
+    def tfhe_key_export(self, h, which, dst):
+        blob = self.be.key_export(self.ctx(h)["h"], int(which))
+        if dst.i + blob.size > len(dst.a):
+            raise MockError(-1, "export buffer shorter than tfhe_key_size")
+        dst.a[dst.i:dst.i + blob.size] = [np.uint8(x) for x in blob.tolist()]
+        self.calls.append(("key_export", int(which), int(blob.size)))
+        return 0
+
+    def tfhe_key_import(self, h, which, src, nbytes):
+        self.be.key_import(self.ctx(h)["h"], int(which), self.read(src, int(nbytes), np.uint8))
+        self.calls.append(("key_import", int(which), int(nbytes)))
         return 0
 
     def tfhe_gate_batch(self, h, ops, op_uniform, a, b, cc, out, B):
