@@ -267,6 +267,35 @@ def test_oracle_full_size_uint5_pbs_agrees_with_the_reference_source(oracle, uin
         assert np.array_equal(out, f["lwe_out"]), name
 
 
+UINT_SETS = [("uint1", 2), ("uint2", 4), ("uint3", 8), ("uint4", 16)]
+
+
+def _uint_key(oracle, level, m):
+    p = oracle.params(level)
+    rng = oracle.rng(0x7F4E0300 + m)
+    s0, s1 = oracle.keygen_secret(p, rng)
+    _, bsk_f = oracle.keygen_bsk(p, rng, s0, s1, torus=False, fourier=True)
+    return p, s0, bsk_f, oracle.keygen_ksk(p, rng, s0, s1)
+
+
+def _check_uint_pbs(oracle, p, s0, out, f, m):
+    want = (3 * int(f["msg"]) + 1) % m
+    assert oracle.decrypt_message(p, m, s0, out) == want == int(f["dec"])
+    scale = (1 << 31) // m
+    d = (int(oracle.phase(p, s0, out)) - want * scale) & 0xFFFFFFFF
+    assert min(d, (1 << 32) - d) < (1 << 32) // (4 * m), d
+
+
+@pytest.mark.parametrize("level,m", UINT_SETS)
+def test_oracle_full_size_pbs_at_the_other_uint_sets_equals_the_reference_source(oracle, level, m):
+    f = load(f"full{level}_pbs")
+    p, s0, bsk_f, ksk = _uint_key(oracle, level, m)
+    assert np.array_equal(oracle.lut_generate(p, [(3 * x + 1) % m for x in range(m)]), f["lut"])
+    out = oracle.bootstrap(p, bsk_f, ksk, f["lwe_in"], f["lut"])
+    _check_uint_pbs(oracle, p, s0, out, f, m)
+    assert np.array_equal(out, f["lwe_out"]), level          # the same operations on the same doubles: identical words
+
+
 # ------------------------------------------------------------------------------------------------------------------ GPU tier: HIP engine
 @pytest.mark.gpu
 def test_gpu_transforms_agree_with_the_reference_source(pkg, ck_small):
@@ -379,6 +408,20 @@ def test_gpu_external_products_at_the_other_exact_shapes_equal_the_reference_sou
             assert np.array_equal(ck.ctx.external_product_batch(0, z[f"in_{level}"][None])[0], z[f"extprod_{level}"]), level
         finally:
             ck.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,m", UINT_SETS)
+def test_gpu_full_size_pbs_at_the_other_uint_sets_agrees_with_the_reference_source(pkg, oracle, level, m):
+    from conftest import gpu_params
+    f = load(f"full{level}_pbs")
+    p, s0, bsk_f, ksk = _uint_key(oracle, level, m)
+    ck = pkg.CloudKey(gpu_params(pkg, p), bsk_fourier=bsk_f, ksk=ksk)
+    try:
+        out = ck.ctx.bootstrap_batch(f["lwe_in"][None], f["lut"])[0]
+        _check_uint_pbs(oracle, p, s0, out, f, m)            # tolerance regime: decryption + phase
+    finally:
+        ck.close()
 
 
 @pytest.mark.gpu

@@ -515,6 +515,33 @@ def job_full(spec):
         save(f"full80_gate_{arg}", a=a[0], b=b[0], bits=bits[:, 0].astype(np.uint8), out=R.u32(r.v.f["P"]),
              meta=R.meta(f"gates.{arg} at the FULL 80-bit set (n = 550, N = 1024: BASELINE configs[0]) with keys80 (tests/conftest.py, seed 0x7F4E0001); inputs from the "
                          "oracle harness, seed 0x7F4E00C9"))
+    elif kind == "pbsu":
+        # one programmable bootstrap at FULL size at each remaining Uint set of params.go (Uint1: N = 1024, L = 2; Uint2: N = 512; Uint3: L = 1, Bgbit = 23;
+        # Uint4: N = 2048), message modulus 2 / 4 / 8 / 16, through the table of f(x) = (3x + 1) mod m
+        level, m = arg
+        o = oracle()
+        p = o.params(level)
+        seed = 0x7F4E0300 + m
+        rng = o.rng(seed)
+        s0, s1 = o.keygen_secret(p, rng)
+        _, bsk_f = o.keygen_bsk(p, rng, s0, s1, torus=False, fourier=True)
+        ksk = o.keygen_ksk(p, rng, s0, s1)
+        R = Ref(level)
+        ck = R.cloudkey(bsk_f, ksk)
+        gen = R.I.call_func("lut", "NewGenerator", m)
+        table = R.I.call_func("lut", "NewLookUpTable")
+        R.I.call_method(gen, "GenLookUpTableAssign", (lambda a_, m=m: (3 * int(a_[0]) + 1) % m), table)
+        erng = o.rng(seed + 1)
+        msg = m - 1
+        ct = o.encrypt_message(p, erng, msg, m, s0)
+        ev = R.I.call_func("evaluator", "NewEvaluator", R.N)
+        res = R.new_lwe()
+        R.I.call_method(ev, "BootstrapLUTAssign", R.lwe(ct), table, ck.v.f["BootstrappingKey"], ck.v.f["KeySwitchingKey"], R.offset, res)
+        outp = R.u32(res.v.f["P"])
+        save(f"full{level}_pbs", lwe_in=ct, msg=np.int64(msg), modulus=np.int64(m), lut=R.trlwe_np(table.v.f["Poly"]), lwe_out=outp, key_seed=np.int64(seed),
+             dec=np.int64(o.decrypt_message(p, m, s0, outp)),
+             meta=R.meta(f"Evaluator.BootstrapLUTAssign at the FULL {level} set (n = {p.n}, N = {p.N}) through the table of (3x + 1) mod {m}; key from the oracle harness, "
+                         f"seed 0x{seed:X}; tolerance regime for the engine (decryption and phase), same-doubles restatement for the oracle"))
     elif kind == "gate110":
         # the third gate set of params.go (110-bit, "original TFHE reference parameters": n = 630), one gate at full size
         o = oracle()
@@ -578,7 +605,8 @@ SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chai
          "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
          "go_golden_program": job_go_golden_program}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
-       [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")]
+       [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")] + \
+       [("pbsu", ("uint1", 2)), ("pbsu", ("uint2", 4)), ("pbsu", ("uint3", 8)), ("pbsu", ("uint4", 16))]
 
 
 def run_small(name):
