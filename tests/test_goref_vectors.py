@@ -119,6 +119,15 @@ def test_oracle_external_product_cmux_and_chain_equal_the_reference_source(oracl
         assert np.array_equal(oracle.blind_rotate(k.p.small(K), k.bsk[:K], ct, k.tv), e["chain_acc"][j]), K
 
 
+def test_oracle_sample_extract_and_key_switch_equal_the_reference_source(oracle, keys_small):
+    z = load("extract_keyswitch_n24_128")
+    k = keys_small
+    for acc, ext, out in zip(z["accs"], z["extracted"], z["switched"]):
+        got = oracle.sample_extract(acc)
+        assert np.array_equal(got, ext)                     # trlwe_ops.go:10-21 (the "negation" is the bitwise complement)
+        assert np.array_equal(oracle.key_switch(k.p, k.ksk, got), out)
+
+
 def test_oracle_reproduces_the_reference_from_the_references_own_keys(oracle):
     # key.NewSecretKey + cloudkey.NewCloudKey + EncryptBool ran under the interpreter (n = 2); the oracle, given the keys the REFERENCE
     # generated, must reproduce the reference's gate outputs and decryptions
@@ -316,6 +325,12 @@ def test_gpu_external_product_and_chain_equal_the_reference_source(pkg, keys_sma
     for j, K in enumerate((1, 2, 4)):
         full[:K], full[-1] = lwe[:K], lwe[-1]
         assert np.array_equal(ck_small.ctx.blind_rotate_batch(full[None], None, K)[0], e["chain_acc"][j]), K
+
+
+@pytest.mark.gpu
+def test_gpu_extract_keyswitch_equals_the_reference_source(pkg, keys_small, ck_small):
+    z = load("extract_keyswitch_n24_128")
+    assert np.array_equal(ck_small.ctx.extract_keyswitch_batch(z["accs"]), z["switched"])
 
 
 @pytest.mark.gpu

@@ -298,6 +298,34 @@ def job_extprod_chain(_):
     save("extprod_chain_128", **out)
 
 
+def job_extract_keyswitch(_):
+    """trlwe.SampleExtractIndexAssign(., 0, .) (trlwe/trlwe_ops.go:10-21) and trgsw.IdentityKeySwitchingAssign (trgsw/keyswitch.go:10-37) on their own:
+    random accumulators (incl. all-zero and all-ones words, whose digits are the k = 0 / k = base-1 edge cases) with keys_small's key-switching key."""
+    o = oracle()
+    p = o.params("128").small(24)
+    rng = o.rng(KEY_SEED_SMALL)
+    s0, s1 = o.keygen_secret(p, rng)
+    o.keygen_bsk(p, rng, s0, s1, torus=True, fourier=True)
+    ksk = o.keygen_ksk(p, rng, s0, s1)
+    R = Ref("128", n_override=24)
+    rs = np.random.RandomState(31)
+    accs = rs.randint(0, 2**32, (3, 2, R.N), dtype=np.uint64).astype(np.uint32)
+    accs[1, 0, :8] = 0
+    accs[1, 0, 8:16] = 0xFFFFFFFF
+    accs[2] = 0
+    kskg = R.ksk(ksk)
+    exts, outs = [], []
+    for acc in accs:
+        ext = R.I.call_func("tlwe", "NewTLWELv1")
+        R.I.call_func("trlwe", "SampleExtractIndexAssign", R.trlwe(acc), 0, ext)
+        out = R.new_lwe()
+        R.I.call_func("trgsw", "IdentityKeySwitchingAssign", ext, kskg, out)
+        exts.append(R.u32(ext.v.f["P"]))
+        outs.append(R.u32(out.v.f["P"]))
+    save("extract_keyswitch_n24_128", accs=accs, extracted=np.stack(exts), switched=np.stack(outs),
+         meta=R.meta("trlwe.SampleExtractIndexAssign + trgsw.IdentityKeySwitchingAssign with keys_small (128-bit ring, n = 24, seed 0x7F4E0003)"))
+
+
 def job_small_bootstrap(_):
     """Whole bootstraps and gates at the 128-bit ring with n = 24 (keys_small): BootstrapAssign, every gates.* function and MUX."""
     o = oracle()
@@ -603,7 +631,7 @@ def job_full(spec):
 
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
          "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
-         "go_golden_program": job_go_golden_program}
+         "go_golden_program": job_go_golden_program, "extract_keyswitch": job_extract_keyswitch}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
        [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")] + \
        [("pbsu", ("uint1", 2)), ("pbsu", ("uint2", 4)), ("pbsu", ("uint3", 8)), ("pbsu", ("uint4", 16))]
