@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Differential fuzzer: libtfhe_hip.so against the C oracle, for as many minutes as asked.
+
+    python tools/fuzz_gpu.py --minutes 10 --seed 1 [--log gpurun_out/fuzz.txt]
+
+Every case draws a parameter set, a (reduced) LWE dimension, a batch size weighted towards the dispatch boundaries of
+the library (1, the CU count, the slab and chunk sizes, +-1 around each), the entry point (gates with one op / one op per
+item incl. MUX / programmable bootstraps through one table or one per item / blind rotate + key switch on their own; host
+pointers or device pointers) and the kernel-dispatch options (TFHE_OPT_QUAD_MAX / OCT_MAX / KS_MFMA_MIN), then runs the same
+words through the oracle:
+
+  * N = 1024, L = 3, Bgbit = 6 sets (80 / 110 / 128-bit): the inputs are ARBITRARY words (no valid encryption needed: the
+    transforms are exact there) with edge rows mixed in, and every output word must be IDENTICAL;
+  * Uint sets (tolerance regime): valid encryptions of random messages; the key switch on its own must be identical (integer
+    work), a programmable bootstrap must decrypt to table[message], its accumulator's phase must sit within the
+    decomposition-noise bound of the oracle's, and its output must be the (exact) key switch of its own accumulator.
+
+Test infrastructure (imports oracle/ through tests/oracle_lib.py); the product never sees it.  Exit status 1 on the first
+mismatch, after writing the case's seed and a repro line."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import __graft_entry__ as graft  # noqa: E402
+
+OPS2 = ["NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN"]
+EXACT = ["80", "110", "128"]
+UINT = {"uint1": 2, "uint2": 4, "uint3": 8, "uint4": 16, "uint5": 32}
+
+
+class Key:
+    def __init__(self, o, pkg, name, n, seed):
+        import torch  # noqa: F401  (device memory for the _dev entry points)
+        self.o, self.name = o, name
+        self.p = o.params(name).small(n)
+        rng = o.rng(seed)
+        self.rng = rng
+        self.s0, self.s1 = o.keygen_secret(self.p, rng)
+        _, self.bsk = o.keygen_bsk(self.p, rng, self.s0, self.s1, torus=False, fourier=True)
+        self.ksk = o.keygen_ksk(self.p, rng, self.s0, self.s1)
+        self.tv = o.gate_testvec(self.p)
+        p = self.p
+        self.ck = pkg.CloudKey(pkg.Params(n=p.n, N=p.N, Nbit=p.Nbit, L=p.L, Bgbit=p.Bgbit, basebit=p.basebit, t=p.t),
+                               bsk_fourier=self.bsk, ksk=self.ksk)
+        self.ctx = self.ck.ctx
+
+
+def words(rs, shape):
+    return rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
+
+
+def edge_rows(rs, a):
+    """Overwrite a few rows with the inputs mod-switch and rotation edge cases come from."""
+    B = a.shape[0]
+    for v in (0, 0xFFFFFFFF, 0x80000000, 0x7FFFFFFF, 0x001FFFFF, 0x00100000, 0xFFF00000):
+        if B and rs.rand() < 0.5:
+            a[rs.randint(B)] = v
+    if B and rs.rand() < 0.5:
+        a[rs.randint(B), -1] = rs.choice([0, 0xFFFFFFFF, 0xFFEFFFFF, 0xFFF00000, 0x000FFFFF, 0x00100000])
+    return a
+
+
+def pick_batch(rs, cus, heavy):
+    marks = [1, 2, 3, cus // 2, cus, 2 * cus, 3 * cus, 4 * cus, 8 * cus, 1000, 1024, 4096]
+    r = rs.rand()
+    if r < 0.45:
+        b = rs.choice(marks) + rs.randint(-2, 3)
+    elif r < 0.8:
+        b = rs.randint(1, 2 * cus + 2)
+    else:
+        b = rs.randint(1, 4200)
+    b = int(max(1, b))
+    return min(b, 1200) if heavy else b
+
+
+def set_options(rs, ctx, log):
+    opts = {"quad_max": rs.choice([-1, -1, 0, 1, 7, 64, 300, 5000]),
+            "oct_max": rs.choice([-1, -1, 0, 1, 5, 64, 300]),
+            "ks_mfma_min": rs.choice([-1, -1, 0, 1, 24, 100, 10**6])}
+    for k, v in opts.items():
+        ctx.set_option(k, int(v))
+    log.append("opts=" + ",".join(f"{k}:{int(v)}" for k, v in opts.items()))
+
+
+def case_exact(rs, o, K, log):
+    import torch
+    p, ctx = K.p, K.ctx
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    kind = rs.choice(["gate1", "gates", "gates_dev", "pbs", "pbs_items", "rotate_ks"], p=[.2, .3, .15, .1, .1, .15])
+    B = pick_batch(rs, cus, heavy=p.n > 40)
+    log.append(f"kind={kind} B={B}")
+    set_options(rs, ctx, log)
+    n1 = p.n + 1
+    if kind in ("gate1", "gates", "gates_dev"):
+        a, b, c = (edge_rows(rs, words(rs, (B, n1))) for _ in range(3))
+        if kind == "gate1":
+            op = str(rs.choice(OPS2 + ["MUX"]))
+            log.append("op=" + op)
+            want, _ = o.gate_batch(p, K.bsk, K.ksk, op, a, b, c if op == "MUX" else None)
+            got = ctx.gate_batch(op, a, b, c if op == "MUX" else None)
+        else:
+            ops = rs.randint(0, 11, B).astype(np.uint8)
+            want, _ = o.gate_batch(p, K.bsk, K.ksk, ops, a, b, c)
+            if kind == "gates":
+                got = ctx.gate_batch(ops, a, b, c)
+            else:
+                dev = lambda x: torch.from_numpy(x.view(np.int32)).cuda()
+                d_out = torch.empty((B, n1), dtype=torch.int32, device="cuda")
+                s = torch.cuda.Stream()
+                with torch.cuda.stream(s):
+                    d_ops, d_a, d_b, d_c = torch.from_numpy(ops).cuda(), dev(a), dev(b), dev(c)
+                    ctx.gate_batch_dev(d_ops, d_a, d_b, d_c, d_out, stream=s)
+                s.synchronize()
+                ctx.sync()
+                got = d_out.cpu().numpy().view(np.uint32)
+        return np.array_equal(got, want), "gate words differ"
+    if kind in ("pbs", "pbs_items"):
+        cts = edge_rows(rs, words(rs, (B, n1)))
+        tv = words(rs, (B, 2, p.N)) if kind == "pbs_items" else words(rs, (2, p.N))
+        if rs.rand() < 0.3:
+            tv[..., 0, :] = 0                    # a look-up table proper: A = 0 (lut/generator.go)
+        want, _ = o.bootstrap_batch(p, K.bsk, K.ksk, cts, tv)
+        got = ctx.bootstrap_batch(cts, tv)
+        return np.array_equal(got, want), "bootstrap words differ"
+    cts = edge_rows(rs, words(rs, (min(B, 600), n1)))
+    nsteps = int(rs.choice([-1, 0, 1, p.n // 2]))
+    log.append(f"nsteps={nsteps}")
+    acc = ctx.blind_rotate_batch(cts, K.tv, nsteps=nsteps)
+    for i in rs.choice(len(cts), size=min(len(cts), 24), replace=False):
+        if not np.array_equal(acc[i], o.blind_rotate(p, K.bsk, cts[i], K.tv, nsteps)):
+            return False, f"accumulator {i} differs"
+    trl = words(rs, (B, 2, p.N))
+    got = ctx.extract_keyswitch_batch(trl)
+    for i in rs.choice(B, size=min(B, 64), replace=False):
+        if not np.array_equal(got[i], o.key_switch(p, K.ksk, o.sample_extract(trl[i]))):
+            return False, f"key switch {i} differs"
+    return True, ""
+
+
+def case_uint(rs, o, K, log):
+    import torch
+    p, ctx, m = K.p, K.ctx, UINT[K.name]
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B = min(pick_batch(rs, cus, heavy=True), 700)
+    log.append(f"kind=uint B={B} m={m}")
+    set_options(rs, ctx, log)
+    trl = words(rs, (B, 2, p.N))
+    got = ctx.extract_keyswitch_batch(trl)
+    for i in rs.choice(B, size=min(B, 32), replace=False):
+        if not np.array_equal(got[i], o.key_switch(p, K.ksk, o.sample_extract(trl[i]))):
+            return False, f"key switch {i} differs"
+    table = rs.randint(0, m, m)
+    tv = o.lut_generate(p, [int(x) for x in table])
+    msgs = rs.randint(0, m, B)
+    cts = np.stack([o.encrypt_message(p, K.rng, int(x), m, K.s0) for x in msgs])
+    out = ctx.bootstrap_batch(cts, tv)
+    dec = np.array([o.decrypt_message(p, m, K.s0, r) for r in out])
+    if not np.array_equal(dec, table[msgs]):
+        return False, "a programmable bootstrap decrypts to the wrong entry"
+    # Tolerance regime: the first decomposition digit that rounds the other way adds a different key row, whose mask is uniform, so
+    # from then on the engine's and the oracle's accumulators are DIFFERENT ENCRYPTIONS of (nearly) the same phase -- their words
+    # are unrelated, and behind the key switch even the phases part by two independent rounding noises (measured 2^-7.8 at Uint2,
+    # 2^-13.3 at Uint5: sqrt(2) x sqrt(N/2) x 2^-(basebit t)/sqrt(12), as the theory says).  What IS comparable:
+    #   (1) the accumulator's phase under the ring key at the extracted coefficient: apart by the decomposition noise of the
+    #       steps only, sigma = 2^-Bgbit sqrt((1 + N/2)/12) per step with a set key bit; bound 8 sigma sqrt(2 n) + 2^-20;
+    #   (2) the key switch, integer work: the oracle's key switch of the ENGINE's accumulator must equal the engine's output.
+    acc = ctx.blind_rotate_batch(cts, tv)
+    s1 = K.s1.astype(np.int64)
+    ph1 = lambda ext: (int(ext[-1]) - int((ext[:-1].astype(np.int64) * s1).sum())) % 2**32
+    bound = 8.0 * 2.0 ** -p.Bgbit * ((1 + p.N / 2) / 12.0) ** 0.5 * (2.0 * p.n) ** 0.5 + 2.0 ** -20
+    for i in rs.choice(B, size=min(B, 8), replace=False):
+        ext = o.sample_extract(acc[i])
+        if not np.array_equal(o.key_switch(p, K.ksk, ext), out[i]):
+            return False, f"item {i}: the fused path's output is not the key switch of its own accumulator"
+        want = o.sample_extract(o.blind_rotate(p, K.bsk, cts[i], tv))
+        d = ((ph1(ext) - ph1(want) + 2**31) % 2**32 - 2**31) / 2.0**32
+        if abs(d) > bound:
+            return False, f"item {i}: accumulator phase {d:+.2e} away from the oracle's (bound {bound:.2e})"
+    return True, ""
+
+
+def run(seconds, seed, say, only_case=None):
+    """Runs cases for `seconds` (or the one case `only_case`); returns (cases, stats); raises AssertionError with the repro
+    line on the first mismatch."""
+    graft.build()
+    pkg = graft.load_package()
+    from oracle_lib import Oracle
+    o = Oracle()
+    keys = {}
+
+    def key(name, n):
+        if (name, n) not in keys:
+            keys[(name, n)] = Key(o, pkg, name, n, 0x7F4E0F00 + 97 * n + sum(map(ord, name)))
+        return keys[(name, n)]
+
+    t0 = time.time()
+    stats = {}
+    k = only_case if only_case is not None else 0
+    try:
+        while True:
+            rs = np.random.RandomState((seed * 1000003 + k) % 2**32)
+            log = []
+            if rs.rand() < 0.85:
+                name, n = str(rs.choice(EXACT)), int(rs.choice([1, 2, 5, 16, 24, 33, 64]))
+                ok, why = case_exact(rs, o, key(name, n), log)
+            else:
+                name, n = str(rs.choice(list(UINT))), int(rs.choice([4, 12]))
+                ok, why = case_uint(rs, o, key(name, n), log)
+            kind = log[0].split()[0]
+            stats[kind] = stats.get(kind, 0) + 1
+            say(f"case {k}: set={name} n={n} {' '.join(log)} -> {'ok' if ok else 'MISMATCH: ' + why}")
+            if not ok:
+                raise AssertionError(f"case {k} ({name}, n={n}, {' '.join(log)}): {why}; "
+                                     f"REPRO: python tools/fuzz_gpu.py --seed {seed} --case {k}")
+            k += 1
+            if only_case is not None or time.time() - t0 > seconds:
+                break
+    finally:
+        for K in keys.values():
+            K.ck.close()
+    say(f"{k if only_case is None else 1} cases in {time.time() - t0:.0f} s, 0 mismatches; by kind: {stats}; contexts: {len(keys)}")
+    return k, stats
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=2.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--log", default=None)
+    ap.add_argument("--case", type=int, default=None, help="run this one case (repro)")
+    a = ap.parse_args()
+    out = open(a.log, "w") if a.log else sys.stdout
+    say = lambda s: (out.write(s + "\n"), out.flush())
+    try:
+        run(a.minutes * 60, a.seed, say, a.case)
+    except AssertionError as e:
+        say(str(e))
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
