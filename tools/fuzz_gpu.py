@@ -7,7 +7,7 @@ Every case draws a parameter set, a (reduced) LWE dimension, a batch size weight
 the library (1, the CU count, the slab and chunk sizes, +-1 around each), the entry point (gates with one op / one op per
 item incl. MUX / programmable bootstraps through one table or one per item / blind rotate + key switch on their own; host
 pointers or device pointers; T concurrent threads of dependent scalar-sized calls; now and then on a tfhe_ctx_clone_to replica, now
-and then at the FULL LWE dimension) and the kernel-dispatch options (TFHE_OPT_QUAD_MAX / OCT_MAX / KS_MFMA_MIN), then runs the same
+and then at the FULL LWE dimension; random levelised circuits through the CircuitExecutor, re-levelled and hipGraph-captured) and the kernel-dispatch options (TFHE_OPT_QUAD_MAX / OCT_MAX / KS_MFMA_MIN), then runs the same
 words through the oracle:
 
   * N = 1024, L = 3, Bgbit = 6 sets (80 / 110 / 128-bit): the inputs are ARBITRARY words (no valid encryption needed: the
@@ -197,6 +197,69 @@ def case_exact(rs, o, K, log):
     return True, ""
 
 
+def case_circuit(rs, o, K, log):
+    """A random levelised circuit (any op incl. MUX, operands from any earlier wire) for C instances through the CircuitExecutor --
+    as given, re-levelled by balance_levels / schedule_min_cost, eager or as a captured hipGraph replayed -- against the oracle
+    evaluating the ORIGINAL gate list one level at a time: every wire identical (wires are single-assignment, so any topological
+    levelling must compute the same words)."""
+    import torch
+    from go_tfhe_amd.circuits import CircuitExecutor, balance_levels, schedule_min_cost
+    p, ctx = K.p, K.ctx
+    n1 = p.n + 1
+    W = int(rs.randint(2, 9))
+    D = int(rs.randint(1, 7))
+    C = int(rs.choice([1, 2, 7, 64, 130]))
+    how = str(rs.choice(["as-given", "balanced", "min-cost", "captured", "captured-min-cost"]))
+    log.append(f"kind=circuit C={C} depth={D} how={how}")
+    set_options(rs, ctx, log)
+    levels, nxt = [], W
+    for _ in range(D):
+        lvl = []
+        avail = nxt                                 # operands come from wires of EARLIER levels
+        for _ in range(int(rs.randint(1, 7))):
+            op = str(rs.choice(OPS2 + ["MUX"]))
+            i0, i1, i2 = (int(x) for x in rs.randint(0, avail, 3))
+            lvl.append((op, i0, i1, i2 if op == "MUX" else None, nxt))
+            nxt += 1
+        levels.append(lvl)
+    log.append(f"gates={sum(len(l) for l in levels)}")
+    run_levels = levels
+    if how == "balanced":
+        run_levels = balance_levels(levels, int(rs.choice([1, 4, 1000])))
+    elif how in ("min-cost", "captured-min-cost"):
+        run_levels = schedule_min_cost(levels, C)
+    if sorted(g[4] for l in run_levels for g in l) != list(range(W, nxt)):
+        return False, "the re-levelled circuit lost or duplicated a gate"
+    inputs = edge_rows(rs, words(rs, (W * C, n1))).reshape(W, C, n1)
+    wires = torch.zeros((nxt, C, n1), dtype=torch.int32, device="cuda")
+    wires[:W] = torch.from_numpy(inputs.view(np.int32)).cuda()
+    ex = CircuitExecutor(ctx, run_levels, nxt)
+    if how.startswith("captured"):
+        graph = ex.capture(wires)
+        try:
+            wires[W:] = 0                           # the replay must recompute every wire from the inputs
+            graph.replay()
+            torch.cuda.synchronize()
+            ctx.sync()
+        finally:
+            del graph
+            ex.release()
+    else:
+        ex.run(wires)
+        torch.cuda.synchronize()
+        ctx.sync()
+    got = wires.cpu().numpy().view(np.uint32)
+    val = {w: inputs[w] for w in range(W)}
+    for lvl in levels:
+        for op, i0, i1, i2, out in lvl:
+            val[out], _ = o.gate_batch(p, K.bsk, K.ksk, op, np.ascontiguousarray(val[i0]), np.ascontiguousarray(val[i1]),
+                                       np.ascontiguousarray(val[i2]) if i2 is not None else None)
+    for w in range(W, nxt):
+        if not np.array_equal(got[w], val[w]):
+            return False, f"wire {w} differs"
+    return True, ""
+
+
 def case_uint(rs, o, K, log):
     import torch
     p, ctx, m = K.p, K.ctx, UINT[K.name]
@@ -280,7 +343,10 @@ def run(seconds, seed, say, only_case=None):
                 name, n = str(rs.choice(EXACT)), int(rs.choice([1, 2, 5, 16, 24, 33, 64]))
                 if rs.rand() < 0.04:
                     n = FULL_N[name]                       # the parameter set as the reference ships it
-                ok, why = case_exact(rs, o, key(name, n), log)
+                if n <= 33 and rs.rand() < 0.12:
+                    ok, why = case_circuit(rs, o, key(name, n), log)
+                else:
+                    ok, why = case_exact(rs, o, key(name, n), log)
             else:
                 name, n = str(rs.choice(list(UINT))), int(rs.choice([4, 12]))
                 ok, why = case_uint(rs, o, key(name, n), log)
