@@ -334,3 +334,18 @@ def test_recorded_runs_of_the_references_slow_unit_tests():
     for pkg_name, p in rec["packages"].items():
         bad = {k: v["failures"] for k, v in p["tests"].items() if v["failures"]}
         assert not bad, (pkg_name, bad)
+
+
+def test_recorded_run_of_the_references_uint_parameter_tests():
+    """params/uint_params_test.go (keygen, lut.Generator, Evaluator.BootstrapLUT through identity / complement / modulo tables at Uint1-5,
+    DecryptLWEMessage): the reference's own test of BASELINE config 4's path, executed offline by the interpreter at LWE dimension 2."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "goref", "reference_tests_uint.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/goref/reference_tests_uint.json not generated (make_goref_vectors.py --jobs reference_tests_uint)")
+    rec = json.load(open(path))
+    assert "NOT the Go toolchain" in rec["what"]
+    for name in ("TestUintParameterProperties", "TestAllUintParameters"):
+        assert rec["tests"][name]["failures"] == [], (name, rec["tests"][name]["failures"])
+        assert not rec["tests"][name]["skipped"]
+    assert rec["tests"]["TestAllUintParameters"]["statements"] > 10**6          # it did run the bootstraps

@@ -441,6 +441,32 @@ def job_reference_tests(_):
     print("[goref] wrote tests/golden/goref/reference_tests.json", flush=True)
 
 
+def job_reference_tests_uint(_):
+    """params/uint_params_test.go -- the reference's own test of the programmable-bootstrap path at the Uint sets (BASELINE config 4's home:
+    keygen, lut.Generator, Evaluator.BootstrapLUT through identity / complement / modulo tables, DecryptLWEMessage) -- under the interpreter.
+    TestUintParameterProperties runs as it is; TestAllUintParameters with the LWE dimension of Uint1-5 set to 2 (each subtest generates a cloud
+    key; Uint6-8 are skipped by the reference itself)."""
+    out = {}
+    I = gi.Interp(REF, seed=0x7F4E00F4)
+    t0 = time.time()
+    out["TestUintParameterProperties"] = I.run_reference_tests("params", only={"TestUintParameterProperties"})["TestUintParameterProperties"]
+    print(f"[goref] TestUintParameterProperties: {out['TestUintParameterProperties']['failures']} {time.time() - t0:.0f} s", flush=True)
+    I = gi.Interp(REF, seed=0x7F4E00F5)
+    params = I.load("params")
+    for m in range(1, 6):
+        I.pkg_value(params, f"paramsUint{m}").f["TLWELv0"].f["N"] = 2
+    t0 = time.time()
+    res = I.run_reference_tests("params", only={"TestAllUintParameters"})["TestAllUintParameters"]
+    res["seconds"] = round(time.time() - t0)
+    res["n_override"] = 2
+    out["TestAllUintParameters"] = res
+    print(f"[goref] TestAllUintParameters: failures {res['failures']} skipped {res['skipped']} {res['statements']} statements {time.time() - t0:.0f} s", flush=True)
+    with open(os.path.join(OUT, "reference_tests_uint.json"), "w") as fh:
+        json.dump({"what": "params/uint_params_test.go executed by tools/go_static/gointerp.py (NOT the Go toolchain); TestAllUintParameters with the LWE "
+                           "dimension of Uint1-5 set to 2", "tests": out}, fh, indent=1)
+    print("[goref] wrote tests/golden/goref/reference_tests_uint.json", flush=True)
+
+
 def job_go_golden_program(_):
     """tools/go_golden/main.go -- the program that pins parity the day someone runs it with the Go toolchain -- EXECUTED by the interpreter
     (os / flag / encoding/binary stand-ins; the LWE dimension of both parameter sets set to 2 so that cloudkey.NewCloudKey is minutes, not
@@ -631,7 +657,8 @@ def job_full(spec):
 
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
          "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
-         "go_golden_program": job_go_golden_program, "extract_keyswitch": job_extract_keyswitch}
+         "go_golden_program": job_go_golden_program, "extract_keyswitch": job_extract_keyswitch,
+              "reference_tests_uint": job_reference_tests_uint}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
        [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")] + \
        [("pbsu", ("uint1", 2)), ("pbsu", ("uint2", 4)), ("pbsu", ("uint3", 8)), ("pbsu", ("uint4", 16))]
