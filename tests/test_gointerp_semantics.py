@@ -349,3 +349,30 @@ def test_recorded_run_of_the_references_uint_parameter_tests():
         assert rec["tests"][name]["failures"] == [], (name, rec["tests"][name]["failures"])
         assert not rec["tests"][name]["skipped"]
     assert rec["tests"]["TestAllUintParameters"]["statements"] > 10**6          # it did run the bootstraps
+
+
+def test_recorded_runs_of_the_references_example_programs():
+    """examples/simple_gates and examples/add_two_numbers (BASELINE config 4's nibble adder), executed as they are, offline, at LWE dimension 2:
+    what the programs print is their verdict."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "goref", "reference_examples.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/goref/reference_examples.json not generated (make_goref_vectors.py --jobs reference_examples)")
+    rec = json.load(open(path, encoding="utf-8"))
+    assert "NOT the Go toolchain" in rec["what"]
+    gates = rec["examples"]["simple_gates"]["result_lines"]
+    verdicts = [l for l in gates if "expected" in l]
+    assert len(verdicts) == 4 * 6 + 2 and all("✅" in l and "❌" not in l for l in verdicts), verdicts
+    adder = rec["examples"]["add_two_numbers"]["result_lines"]
+    assert any(l.startswith("Result:     179") for l in adder) and any("✅ SUCCESS" in l for l in adder), adder
+
+
+def test_print_capture_and_format_verbs():
+    import gointerp as gi
+    I = gi.Interp(ROOT, seed=1)                       # no reference needed: the program imports the fmt stand-in only
+    I.stdout = []
+    src = ('package main\nimport "fmt"\nfunc main() {\n\tfmt.Printf("%3d|%04b|%v|%-5s|%5s|%.2f\\n", 7, 5, true, "ab", "cd", 1.5)\n'
+           '\tfmt.Println("✅", 3, false)\n}\n')
+    pkg = I.load_source("main", {"x.go": src}, path="example.com/x")
+    I.call_decl(pkg.funcs["main"], pkg, [], None)
+    assert I.stdout == ["  7|0101|true|ab   |   cd|1.50\n", "✅ 3 false"]

@@ -508,8 +508,19 @@ class Interp:
         s.native["RWMutex"] = RT("struct", fields=[])
         s.native["Pool"] = RT("struct", fields=[("New", RT("func"))])
         f = mk("fmt")
-        f.native.update({"Sprintf": Builtin(lambda a: self.sprintf(a), "Sprintf"), "Println": Builtin(lambda a: None, "Println"),
-                         "Printf": Builtin(lambda a: None, "Printf")})
+        # fmt.Print*: dropped unless self.stdout is a list (then one entry per call: what a reference PROGRAM prints is its result)
+        self.stdout = None
+        gostr = lambda v: ("true" if v else "false") if isinstance(v, (bool, np.bool_)) else str(v)
+
+        def _println(a):
+            if self.stdout is not None:
+                self.stdout.append(" ".join(gostr(x) for x in a))
+
+        def _printf(a):
+            if self.stdout is not None:
+                self.stdout.append(self.sprintf(a))
+        f.native.update({"Sprintf": Builtin(lambda a: self.sprintf(a), "Sprintf"), "Println": Builtin(_println, "Println"),
+                         "Printf": Builtin(_printf, "Printf"), "Print": Builtin(_println, "Print")})
         r = mk("math/rand", "rand")
         RAND = RT("struct", fields=[])
         r.native["Rand"] = RAND
@@ -599,8 +610,14 @@ class Interp:
                     return format(int(v), m.group(0)[1:-1] + verb)
                 if verb in "feg" and isinstance(v, (int, float, np.generic)):
                     return format(float(v), m.group(0)[1:-1] + verb if m.group(0)[1:-1] else ".6f")
+                if verb in "db" and isinstance(v, (int, np.integer)) and not isinstance(v, (bool, np.bool_)):
+                    return format(int(v), m.group(0)[1:-1] + verb)
+                if isinstance(v, (bool, np.bool_)):
+                    return "true" if v else "false"
+                if verb == "s" and m.group(0)[1:-1]:
+                    return format(str(v), m.group(0)[1:-1].replace("-", "<") if "-" in m.group(0) else ">" + m.group(0)[1:-1])
                 return str(v)
-            return _re.sub(r"%[-+0-9. #]*[vdsfxXtqeg%T]", sub, a[0])
+            return _re.sub(r"%[-+0-9. #]*[vdsfxXtqegb%T]", sub, a[0])
         except Exception:                               # noqa: BLE001
             return str(a)
 
@@ -1073,9 +1090,9 @@ class Interp:
                 elif e.lkind == "float":
                     c = float(t.replace("_", ""))
                 elif e.lkind == "string":
-                    c = t[1:-1] if t[0] == "`" else bytes(t[1:-1], "utf-8").decode("unicode_escape")
+                    c = t[1:-1] if t[0] == "`" or "\\" not in t else t[1:-1].encode("latin-1", "backslashreplace").decode("unicode_escape")
                 else:
-                    c = ord(bytes(t[1:-1], "utf-8").decode("unicode_escape"))
+                    c = ord(t[1:-1].encode("latin-1", "backslashreplace").decode("unicode_escape"))
                 e._c = (c,)
                 return c
             return c[0]

@@ -467,6 +467,30 @@ def job_reference_tests_uint(_):
     print("[goref] wrote tests/golden/goref/reference_tests_uint.json", flush=True)
 
 
+def job_reference_examples(_):
+    """The reference's example PROGRAMS, executed as they are by the interpreter (LWE dimension set to 2: each generates a cloud key), their
+    standard output recorded: examples/add_two_numbers (BASELINE config 4: the nibble adder, three Evaluator.BootstrapLUT at the Uint5 ring,
+    42 + 137 = 179) and examples/simple_gates (every gates.* truth table at the 128-bit ring)."""
+    out = {}
+    for name, lower in (("simple_gates", ["params128Bit"]), ("add_two_numbers", ["paramsUint5"])):
+        I = gi.Interp(REF, seed=0x7F4E00F6)
+        params = I.load("params")
+        for v in lower:
+            I.pkg_value(params, v).f["TLWELv0"].f["N"] = 2
+        I.stdout = []
+        src = os.path.join(REF, "examples", name, "main.go")
+        pkg = I.load_source("main", {src: open(src).read()}, path="github.com/thedonutfactory/go-tfhe/examples/" + name)
+        t0 = time.time()
+        I.call_decl(pkg.funcs["main"], pkg, [], None)
+        keep = [l for l in I.stdout if any(k in l for k in ("\u2705", "\u274c", "Result", "Expected", "Testing inputs", "expected"))]
+        out[name] = {"n_override": 2, "seconds": round(time.time() - t0), "statements": I.steps, "stdout_lines": len(I.stdout), "result_lines": keep}
+        print(f"[goref] example {name}: {len(I.stdout)} lines, {time.time() - t0:.0f} s; " + " | ".join(keep[-3:]), flush=True)
+    with open(os.path.join(OUT, "reference_examples.json"), "w") as fh:
+        json.dump({"what": "go-tfhe's example programs executed by tools/go_static/gointerp.py (NOT the Go toolchain), LWE dimension set to 2; the lines "
+                           "of their standard output that state results", "examples": out}, fh, indent=1, ensure_ascii=False)
+    print("[goref] wrote tests/golden/goref/reference_examples.json", flush=True)
+
+
 def job_go_golden_program(_):
     """tools/go_golden/main.go -- the program that pins parity the day someone runs it with the Go toolchain -- EXECUTED by the interpreter
     (os / flag / encoding/binary stand-ins; the LWE dimension of both parameter sets set to 2 so that cloudkey.NewCloudKey is minutes, not
@@ -658,7 +682,7 @@ def job_full(spec):
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
          "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
          "go_golden_program": job_go_golden_program, "extract_keyswitch": job_extract_keyswitch,
-              "reference_tests_uint": job_reference_tests_uint}
+              "reference_tests_uint": job_reference_tests_uint, "reference_examples": job_reference_examples}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
        [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")] + \
        [("pbsu", ("uint1", 2)), ("pbsu", ("uint2", 4)), ("pbsu", ("uint3", 8)), ("pbsu", ("uint4", 16))]
