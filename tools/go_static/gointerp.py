@@ -19,7 +19,8 @@ immaterial where the transforms are exact, inside the stated tolerance elsewhere
 Value model
   int, int64, uint64, uintptr, untyped constants   Python int (no overflow occurs on these paths)
   uint32 (params.Torus), int32, uint8, uint16 ...   numpy scalars: wrap-around arithmetic, C-style conversions
-  float64 / complex128 / bool / string              Python float / complex / bool / str
+  float64 / complex128 / bool / string              Python float / complex / bool / str (code points, not bytes: len of a non-ASCII
+                                                    string differs from Go's; only the examples' banners hold such text)
   struct value                                      GoStruct (copied on assignment, parameter passing, return, element store)
   *T                                                GoPtr(target) -- field access and method calls dereference automatically
   []T                                               GoSlice(backing list, offset, len, cap): slicing SHARES the backing list
