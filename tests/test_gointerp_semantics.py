@@ -365,6 +365,20 @@ def test_recorded_runs_of_the_references_example_programs():
     assert len(verdicts) == 4 * 6 + 2 and all("✅" in l and "❌" not in l for l in verdicts), verdicts
     adder = rec["examples"]["add_two_numbers"]["result_lines"]
     assert any(l.startswith("Result:     179") for l in adder) and any("✅ SUCCESS" in l for l in adder), adder
+    import re
+    pbs = rec["examples"]["programmable_bootstrap"]["result_lines"]
+    f = {"identity": lambda x: x, "NOT": lambda x: 1 - x, "constant(1)": lambda x: 1, "constant(0)": lambda x: 0}
+    seen = 0
+    for l in pbs:
+        m = re.search(r"→ (.+)\((\d)\) = (\d)", l)
+        if m:
+            assert int(m.group(3)) == f[m.group(1)](int(m.group(2))), l
+            seen += 1
+        m = re.search(r"increment\((\d)\) = (\d) \(expected (\d)\) (.)", l)
+        if m:
+            assert m.group(2) == m.group(3) == str((int(m.group(1)) + 1) % 4) and m.group(4) == "✓", l
+            seen += 1
+    assert seen == 13 + 4, pbs
 
 
 def test_print_capture_and_format_verbs():

@@ -535,7 +535,7 @@ class Interp:
                          "NormFloat64": Builtin(lambda a: float(self.rng.standard_normal()), "NormFloat64")})
         self.RAND = RAND
         t = mk("time")
-        t.native.update({"Now": Builtin(lambda a: 0, "Now"), "Since": Builtin(lambda a: 0, "Since")})
+        t.native.update({"Now": Builtin(lambda a: 0, "Now"), "Since": Builtin(lambda a: 0, "Since"), "Duration": BASIC_RT["int64"]})
         rt_ = mk("runtime")
         rt_.native.update({"NumCPU": Builtin(lambda a: 1, "NumCPU"), "GOMAXPROCS": Builtin(lambda a: 1, "GOMAXPROCS"),
                            "LockOSThread": Builtin(lambda a: None, "LockOSThread"), "UnlockOSThread": Builtin(lambda a: None, "UnlockOSThread")})

@@ -470,9 +470,14 @@ def job_reference_tests_uint(_):
 def job_reference_examples(_):
     """The reference's example PROGRAMS, executed as they are by the interpreter (LWE dimension set to 2: each generates a cloud key), their
     standard output recorded: examples/add_two_numbers (BASELINE config 4: the nibble adder, three Evaluator.BootstrapLUT at the Uint5 ring,
-    42 + 137 = 179) and examples/simple_gates (every gates.* truth table at the 128-bit ring)."""
-    out = {}
-    for name, lower in (("simple_gates", ["params128Bit"]), ("add_two_numbers", ["paramsUint5"])):
+    42 + 137 = 179), examples/simple_gates (every gates.* truth table at the 128-bit ring) and examples/programmable_bootstrap
+    (BootstrapFunc / BootstrapLUT through identity, NOT, constants, a reused table and a 2-bit increment at the 80-bit ring)."""
+    path = os.path.join(OUT, "reference_examples.json")
+    out = json.load(open(path, encoding="utf-8"))["examples"] if os.path.exists(path) else {}
+    only = os.environ.get("GOREF_EXAMPLES")                       # comma-separated subset; the others keep their recorded runs
+    for name, lower in (("simple_gates", ["params128Bit"]), ("add_two_numbers", ["paramsUint5"]), ("programmable_bootstrap", ["params80Bit"])):
+        if only and name not in only.split(","):
+            continue
         I = gi.Interp(REF, seed=0x7F4E00F6)
         params = I.load("params")
         for v in lower:
@@ -482,10 +487,11 @@ def job_reference_examples(_):
         pkg = I.load_source("main", {src: open(src).read()}, path="github.com/thedonutfactory/go-tfhe/examples/" + name)
         t0 = time.time()
         I.call_decl(pkg.funcs["main"], pkg, [], None)
-        keep = [l for l in I.stdout if any(k in l for k in ("\u2705", "\u274c", "Result", "Expected", "Testing inputs", "expected"))]
+        keep = [l.rstrip("\n") for l in I.stdout
+                if any(k in l for k in ("\u2705", "\u274c", "\u2713", "\u2717", "\u2192", "Result", "Expected", "Testing inputs", "expected"))]
         out[name] = {"n_override": 2, "seconds": round(time.time() - t0), "statements": I.steps, "stdout_lines": len(I.stdout), "result_lines": keep}
         print(f"[goref] example {name}: {len(I.stdout)} lines, {time.time() - t0:.0f} s; " + " | ".join(keep[-3:]), flush=True)
-    with open(os.path.join(OUT, "reference_examples.json"), "w") as fh:
+    with open(path, "w", encoding="utf-8") as fh:
         json.dump({"what": "go-tfhe's example programs executed by tools/go_static/gointerp.py (NOT the Go toolchain), LWE dimension set to 2; the lines "
                            "of their standard output that state results", "examples": out}, fh, indent=1, ensure_ascii=False)
     print("[goref] wrote tests/golden/goref/reference_examples.json", flush=True)
