@@ -491,6 +491,31 @@ def job_reference_examples(_):
                 if any(k in l for k in ("\u2705", "\u274c", "\u2713", "\u2717", "\u2192", "Result", "Expected", "Testing inputs", "expected"))]
         out[name] = {"n_override": 2, "seconds": round(time.time() - t0), "statements": I.steps, "stdout_lines": len(I.stdout), "result_lines": keep}
         print(f"[goref] example {name}: {len(I.stdout)} lines, {time.time() - t0:.0f} s; " + " | ".join(keep[-3:]), flush=True)
+    name = "simple_gates_on_the_shim"
+    if not only or name in only.split(","):
+        # The drop-in claim on the reference's own program: examples/simple_gates with ONE line changed in memory -- the import path of
+        # `gates` -> the shim's package ("switch by import path") -- everything else (key.NewSecretKey,
+        # cloudkey.NewCloudKey, tlwe encryption, the program text) the reference's.  cgo's "C" is tools/go_static/cmock.py on the oracle.
+        import cmock
+        MOD = "github.com/thedonutfactory/go-tfhe-gpu"
+        I = gi.Interp(REF, seed=0x7F4E00F6)
+        I.extra_roots = {MOD: os.path.join(ROOT, "shim", "go")}
+        params = I.load("params")
+        I.pkg_value(params, "params128Bit").f["TLWELv0"].f["N"] = 2
+        mock = cmock.MockC(I, oracle(), device_count=2)
+        I.stdout = []
+        src = os.path.join(REF, "examples", "simple_gates", "main.go")
+        text = open(src).read()
+        swapped = text.replace('"github.com/thedonutfactory/go-tfhe/gates"', f'"{MOD}/gates"')
+        assert swapped != text and swapped.count(MOD) == 1
+        pkg = I.load_source("main", {src: swapped}, path="github.com/thedonutfactory/go-tfhe/examples/simple_gates_gpu")
+        t0 = time.time()
+        I.call_decl(pkg.funcs["main"], pkg, [], None)
+        keep = [l.rstrip("\n") for l in I.stdout if any(k in l for k in ("\u2705", "\u274c", "Testing inputs", "expected"))]
+        calls = [c[0] for c in mock.calls]
+        out[name] = {"n_override": 2, "seconds": round(time.time() - t0), "stdout_lines": len(I.stdout), "result_lines": keep,
+                     "c_abi_calls": {k: calls.count(k) for k in sorted(set(calls))}}
+        print(f"[goref] example {name}: {len(I.stdout)} lines, {time.time() - t0:.0f} s; calls {out[name]['c_abi_calls']}; " + " | ".join(keep[-2:]), flush=True)
     with open(path, "w", encoding="utf-8") as fh:
         json.dump({"what": "go-tfhe's example programs executed by tools/go_static/gointerp.py (NOT the Go toolchain), LWE dimension set to 2; the lines "
                            "of their standard output that state results", "examples": out}, fh, indent=1, ensure_ascii=False)
