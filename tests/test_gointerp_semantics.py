@@ -379,6 +379,13 @@ def test_recorded_runs_of_the_references_example_programs():
             assert m.group(2) == m.group(3) == str((int(m.group(1)) + 1) % 4) and m.group(4) == "✓", l
             seen += 1
     assert seen == 13 + 4, pbs
+    # ... and the same two programs with ONE import path switched to the shim (cgo's "C" mocked on the oracle): the same verdicts, through the C ABI
+    g = rec["examples"]["simple_gates_on_the_shim"]
+    verdicts = [l for l in g["result_lines"] if "expected" in l]
+    assert len(verdicts) == 26 and all("✅" in l for l in verdicts) and g["c_abi_calls"]["gate_batch"] == 24 and g["c_abi_calls"]["load_bsk"] == 1
+    a = rec["examples"]["add_two_numbers_on_the_shim"]
+    assert any(l.startswith("Result:     179") for l in a["result_lines"]) and any("✅ SUCCESS" in l for l in a["result_lines"])
+    assert a["c_abi_calls"]["bootstrap_batch"] == 3 and a["c_abi_calls"]["load_ksk"] == 1
 
 
 def test_print_capture_and_format_verbs():

@@ -7,7 +7,8 @@ Every case draws a parameter set, a (reduced) LWE dimension, a batch size weight
 the library (1, the CU count, the slab and chunk sizes, +-1 around each), the entry point (gates with one op / one op per
 item incl. MUX / programmable bootstraps through one table or one per item / blind rotate + key switch on their own; host
 pointers or device pointers; T concurrent threads of dependent scalar-sized calls; now and then on a tfhe_ctx_clone_to replica, now
-and then at the FULL LWE dimension; random levelised circuits through the CircuitExecutor, re-levelled and hipGraph-captured) and the kernel-dispatch options (TFHE_OPT_QUAD_MAX / OCT_MAX / KS_MFMA_MIN), then runs the same
+and then at the FULL LWE dimension; random levelised circuits through the CircuitExecutor, re-levelled and hipGraph-captured;
+the same key brought in as a torus-form upload / imported blobs / a host-staged clone) and the kernel-dispatch options (TFHE_OPT_QUAD_MAX / OCT_MAX / KS_MFMA_MIN), then runs the same
 words through the oracle:
 
   * N = 1024, L = 3, Bgbit = 6 sets (80 / 110 / 128-bit): the inputs are ARBITRARY words (no valid encryption needed: the
@@ -41,12 +42,12 @@ UINT = {"uint1": 2, "uint2": 4, "uint3": 8, "uint4": 16, "uint5": 32}
 class Key:
     def __init__(self, o, pkg, name, n, seed):
         import torch  # noqa: F401  (device memory for the _dev entry points)
-        self.o, self.name = o, name
+        self.o, self.name, self.seed = o, name, seed
         self.p = o.params(name).small(n)
         rng = o.rng(seed)
         self.rng = rng
         self.s0, self.s1 = o.keygen_secret(self.p, rng)
-        self.bsk_torus, self.bsk = o.keygen_bsk(self.p, rng, self.s0, self.s1, torus=name in UINT, fourier=True)
+        self.bsk_torus, self.bsk = o.keygen_bsk(self.p, rng, self.s0, self.s1, torus=True, fourier=True)
         self.ksk = o.keygen_ksk(self.p, rng, self.s0, self.s1)
         self.tv = o.gate_testvec(self.p)
         p = self.p
@@ -197,6 +198,50 @@ def case_exact(rs, o, K, log):
     return True, ""
 
 
+def case_keys(rs, o, pkg, K, log):
+    """The same cloud key brought onto the GPU another way -- uploaded in torus form (the engine transforms it: cloudkey.go:88-110 does
+    that on the CPU), or as the exported blobs imported into a fresh context (host or device blobs), or as a clone staged through host
+    memory -- must give the same words as the Fourier-form upload (and therefore as the oracle, which the other kinds check)."""
+    import torch
+    p, n1 = K.p, K.p.n + 1
+    how = str(rs.choice(["torus-upload", "blob-import", "blob-import-dev", "host-staged-clone"]))
+    B = int(rs.choice([1, 3, 40, 257, 600]))
+    log.append(f"kind=keys B={B} how={how}")
+    P = pkg.Params(n=p.n, N=p.N, Nbit=p.Nbit, L=p.L, Bgbit=p.Bgbit, basebit=p.basebit, t=p.t)
+    other = None
+    try:
+        if how == "torus-upload":
+            other = pkg.CloudKey(P, bsk_torus=K.bsk_torus, ksk=K.ksk)
+            ctx = other.ctx
+        elif how == "host-staged-clone":
+            K.ctx.set_option("clone_force_host", 1)
+            try:
+                other = K.ck.clone_to(0)
+            finally:
+                K.ctx.set_option("clone_force_host", 0)
+            ctx = other.ctx
+            if ctx.get_option("clone_path") != 3:
+                return False, "the forced host-staged clone did not take the host-staged path"
+        else:
+            ctx = pkg.Context(P)
+            other = ctx
+            for which in (0, 1):
+                if how == "blob-import":
+                    ctx.key_import(which, K.ctx.key_export(which))
+                else:
+                    ctx.key_import_dev(which, K.ctx.key_export_dev(which))
+            torch.cuda.synchronize()
+        ops = rs.randint(0, 11, B).astype(np.uint8)
+        a, b, c = (edge_rows(rs, words(rs, (B, n1))) for _ in range(3))
+        got, want = ctx.gate_batch(ops, a, b, c), K.ctx.gate_batch(ops, a, b, c)
+        if K.name in UINT:
+            return True, ""                      # tolerance regime: the torus upload's transform rounds differently; nothing to assert word-wise
+        return np.array_equal(got, want), f"words differ between the key brought by {how} and the Fourier-form upload"
+    finally:
+        if other is not None:
+            other.close()
+
+
 def case_circuit(rs, o, K, log):
     """A random levelised circuit (any op incl. MUX, operands from any earlier wire) for C instances through the CircuitExecutor --
     as given, re-levelled by balance_levels / schedule_min_cost, eager or as a captured hipGraph replayed -- against the oracle
@@ -343,7 +388,9 @@ def run(seconds, seed, say, only_case=None):
                 name, n = str(rs.choice(EXACT)), int(rs.choice([1, 2, 5, 16, 24, 33, 64]))
                 if rs.rand() < 0.04:
                     n = FULL_N[name]                       # the parameter set as the reference ships it
-                if n <= 33 and rs.rand() < 0.12:
+                if n <= 64 and rs.rand() < 0.05:
+                    ok, why = case_keys(rs, o, pkg, key(name, n), log)
+                elif n <= 33 and rs.rand() < 0.12:
                     ok, why = case_circuit(rs, o, key(name, n), log)
                 else:
                     ok, why = case_exact(rs, o, key(name, n), log)

@@ -516,6 +516,30 @@ def job_reference_examples(_):
         out[name] = {"n_override": 2, "seconds": round(time.time() - t0), "stdout_lines": len(I.stdout), "result_lines": keep,
                      "c_abi_calls": {k: calls.count(k) for k in sorted(set(calls))}}
         print(f"[goref] example {name}: {len(I.stdout)} lines, {time.time() - t0:.0f} s; calls {out[name]['c_abi_calls']}; " + " | ".join(keep[-2:]), flush=True)
+    name = "add_two_numbers_on_the_shim"
+    if not only or name in only.split(","):
+        # ... and BASELINE config 4's program: examples/add_two_numbers with the import path of `evaluator` switched to the shim's package
+        # (evaluator.NewEvaluator, eval.BootstrapLUT keep the reference's signatures): three programmable bootstraps through the C ABI.
+        import cmock
+        MOD = "github.com/thedonutfactory/go-tfhe-gpu"
+        I = gi.Interp(REF, seed=0x7F4E00F6)
+        I.extra_roots = {MOD: os.path.join(ROOT, "shim", "go")}
+        params = I.load("params")
+        I.pkg_value(params, "paramsUint5").f["TLWELv0"].f["N"] = 2
+        mock = cmock.MockC(I, oracle(), device_count=1)
+        I.stdout = []
+        src = os.path.join(REF, "examples", "add_two_numbers", "main.go")
+        text = open(src).read()
+        swapped = text.replace('"github.com/thedonutfactory/go-tfhe/evaluator"', f'"{MOD}/evaluator"')
+        assert swapped != text and swapped.count(MOD) == 1
+        pkg = I.load_source("main", {src: swapped}, path="github.com/thedonutfactory/go-tfhe/examples/add_two_numbers_gpu")
+        t0 = time.time()
+        I.call_decl(pkg.funcs["main"], pkg, [], None)
+        keep = [l.rstrip("\n") for l in I.stdout if any(k in l for k in ("\u2705", "\u274c", "Result", "Expected"))]
+        calls = [c[0] for c in mock.calls]
+        out[name] = {"n_override": 2, "seconds": round(time.time() - t0), "stdout_lines": len(I.stdout), "result_lines": keep,
+                     "c_abi_calls": {k: calls.count(k) for k in sorted(set(calls))}}
+        print(f"[goref] example {name}: {len(I.stdout)} lines, {time.time() - t0:.0f} s; calls {out[name]['c_abi_calls']}; " + " | ".join(keep[-3:]), flush=True)
     with open(path, "w", encoding="utf-8") as fh:
         json.dump({"what": "go-tfhe's example programs executed by tools/go_static/gointerp.py (NOT the Go toolchain), LWE dimension set to 2; the lines "
                            "of their standard output that state results", "examples": out}, fh, indent=1, ensure_ascii=False)
