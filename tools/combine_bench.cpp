@@ -60,6 +60,7 @@ static int pbs_mode(int T)
                 "\"one_thread_8_pbs_ms\": %.1f, \"serialised_%d_threads_ms\": %.1f, \"serialised_all_threads_projected_ms\": %.0f}\n",
                 T, 8 * T, ms, l1 - l0, r1 - r0, one, Ts, serial, serial / Ts * T);
     CK(tfhe_ctx_destroy(ctx));
+    std::fflush(stdout);
     return 0;
 }
 
@@ -114,5 +115,6 @@ int main(int argc, char **argv)
                 "\"one_thread_40_gates_ms\": %.1f, \"serialised_%d_threads_ms\": %.1f, \"serialised_all_threads_projected_ms\": %.0f}\n",
                 T, 40 * T, ms, l1 - l0, r1 - r0, one, Ts, serial, serial / Ts * T);
     CK(tfhe_ctx_destroy(ctx));
+    std::fflush(stdout);
     return 0;
 }
