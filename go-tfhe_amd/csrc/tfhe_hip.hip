@@ -974,8 +974,14 @@ int combine_cap(const tfhe_ctx *c, int kind)
 // Waiters sleep on ONE generation word (futex) that every finished launch bumps and wakes: one system call for all of them,
 // no mutex on the wake path.  256 threads x 40 dependent scalar gates: 25 s serialised -> 0.124 s; 256 threads x 8 dependent Uint5
 // bootstraps through their own tables: 8.4 s -> 67 ms (profiles/r04_d_combine.txt).
+#ifdef TFHE_TSAN_CONTROL
+long g_tsan_control;         // tools/asan_host_check.sh control thread: a deliberate unsynchronised counter the ThreadSanitizer build must report
+#endif
 int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
 {
+#ifdef TFHE_TSAN_CONTROL
+    g_tsan_control++;
+#endif
     tfhe_ctx::CombQueue &Q = c->comb[me.kind];
     std::unique_lock<std::mutex> lk(Q.mu);
     Q.pending.push_back(&me);

@@ -1,5 +1,7 @@
 #!/bin/bash
-# tools/asan_host_check.sh build | run   [address | thread]      (default: address)
+# tools/asan_host_check.sh build | run   [address | thread | control]      (default: address)
+# `control` = the thread-sanitizer build with -DTFHE_TSAN_CONTROL (one deliberately unsynchronised counter in combine_request): `run control`
+# SUCCEEDS only if ThreadSanitizer reports that race -- the positive control for "0 reports" of `run thread`.
 # The product's HOST code (csrc/tfhe_hip.hip: staging, grow-only buffers, the combiner's request queue, clone_to, key blobs) under
 # AddressSanitizer; the device code is not instrumented (-fno-gpu-sanitize), the blind-rotate units are the shipped objects' sources
 # at their normal flags.  `build` cross-compiles here (no GPU needed) into go-tfhe_amd/lib/variants/asan/ (git-ignored, travels to the
@@ -8,6 +10,7 @@ set -e
 cd "$(dirname "$0")/.."
 SAN=${2:-address}
 D=go-tfhe_amd/lib/variants/${SAN}san
+CONTROL=""; if [ $SAN = control ]; then SAN=thread; CONTROL=-DTFHE_TSAN_CONTROL; fi
 GPUSAN=""; [ $SAN = address ] && GPUSAN=-fno-gpu-sanitize
 RTNAME=asan; [ $SAN = thread ] && RTNAME=tsan
 HIPCC=/opt/rocm/bin/hipcc
@@ -16,7 +19,7 @@ if [ "$1" = build ]; then
     O=/tmp/${SAN}san_obj; mkdir -p $D $O
     F="--offload-arch=gfx950 -std=c++17 -fPIC"
     ILP="-mllvm -amdgpu-sched-strategy=max-ilp"
-    $HIPCC $F -O1 -g -fsanitize=$SAN $GPUSAN -shared-libsan -Wno-option-ignored -c go-tfhe_amd/csrc/tfhe_hip.hip -o $O/a.o &
+    $HIPCC $F -O1 -g -fsanitize=$SAN $GPUSAN $CONTROL -shared-libsan -Wno-option-ignored -c go-tfhe_amd/csrc/tfhe_hip.hip -o $O/a.o &
     $HIPCC $F -O3 $ILP -c go-tfhe_amd/csrc/blind_rotate.hip -o $O/b.o 2>/dev/null &
     $HIPCC $F -O3 $ILP -mllvm -enable-post-misched=0 -c go-tfhe_amd/csrc/blind_rotate_oct.hip -o $O/c.o 2>/dev/null &
     $HIPCC $F -O3 -c go-tfhe_amd/csrc/blind_rotate_n2048.hip -o $O/d.o 2>/dev/null &
@@ -49,6 +52,15 @@ else
         fi
         echo "ASAN RUN FAILED: $*"; exit 1
     }
+    if [ -n "$CONTROL" ]; then
+        echo "+ $D/combine_bench 64   (control build: a report is EXPECTED)"
+        $D/combine_bench 64 > /tmp/asan_out.txt 2>&1 || true
+        grep -v "^    #" /tmp/asan_out.txt | grep -A 12 "WARNING: ThreadSanitizer: data race" | head -30
+        if grep -q "WARNING: ThreadSanitizer: data race" /tmp/asan_out.txt && grep -q "g_tsan_control" /tmp/asan_out.txt; then
+            echo "control: ThreadSanitizer reports the seeded race in combine_request -- the instrumentation sees this code"; exit 0
+        fi
+        echo "CONTROL FAILED: the seeded race was not reported"; exit 1
+    fi
     run $D/test_host_mirror
     run $D/combine_bench 64
     run $D/combine_bench 256
