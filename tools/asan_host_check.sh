@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/asan_host_check.sh build | run   [address | thread | control]      (default: address)
+# tools/asan_host_check.sh build | run   [address | thread | undefined | control]      (default: address)
 # `control` = the thread-sanitizer build with -DTFHE_TSAN_CONTROL (one deliberately unsynchronised counter in combine_request): `run control`
 # SUCCEEDS only if ThreadSanitizer reports that race -- the positive control for "0 reports" of `run thread`.
 # The product's HOST code (csrc/tfhe_hip.hip: staging, grow-only buffers, the combiner's request queue, clone_to, key blobs) under
@@ -12,7 +12,7 @@ SAN=${2:-address}
 D=go-tfhe_amd/lib/variants/${SAN}san
 CONTROL=""; if [ $SAN = control ]; then SAN=thread; CONTROL=-DTFHE_TSAN_CONTROL; fi
 GPUSAN=""; [ $SAN = address ] && GPUSAN=-fno-gpu-sanitize
-RTNAME=asan; [ $SAN = thread ] && RTNAME=tsan
+RTNAME=asan; [ $SAN = thread ] && RTNAME=tsan; [ $SAN = undefined ] && RTNAME=ubsan_standalone
 HIPCC=/opt/rocm/bin/hipcc
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 if [ "$1" = build ]; then
@@ -37,6 +37,7 @@ else
     # thread: the HIP / HSA runtimes are not instrumented; reports whose frames all lie inside them are theirs (suppressed by library
     # name), every report that touches libtfhe_hip.so's own frames counts
     printf 'called_from_lib:libamdhip64.so\ncalled_from_lib:libhsa-runtime64.so\nrace:libamdhip64.so\nrace:libhsa-runtime64.so\n' > /tmp/tsan.supp
+    export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
     export TSAN_OPTIONS=suppressions=/tmp/tsan.supp:halt_on_error=0:second_deadlock_stack=1:exitcode=66:ignore_noninstrumented_modules=0
     # The ROCm ASan runtime owns a device allocator whose teardown check ("dev_runtime_unloaded_") can fire inside libamdhip64's own
     # exit-time finaliser (__cxa_finalize -> libhsa-runtime64 -> operator delete), after main has returned: that report is about the
