@@ -305,6 +305,31 @@ def case_circuit(rs, o, K, log):
     return True, ""
 
 
+def case_extended(rs, o, K, ext, log):
+    """Programmable bootstraps through an EXTENDED lookup table (polyExtendFactor 2: the persistent eight-wave kernel; 4 and 9: one launch
+    per CMUX step) -- the reference specifies these sets and skips them (params/uint_params_test.go:29-31), so the yardstick is the table:
+    every item must decrypt to table[message]; one table for all items or one per item; batch sizes around the CU count."""
+    from go_tfhe_amd.lut import Generator
+    p, ctx = K.p, K.ctx
+    m = {2: 64, 4: 128, 9: 256}[ext]
+    B = int(rs.choice([1, 3, 64, 255, 256, 257, 300]))
+    per_item = bool(rs.rand() < 0.3) and B <= 64
+    log.append(f"kind=extended ext={ext} m={m} B={B} per_item={int(per_item)}")
+    gen = Generator(p, m, polyExtendFactor=ext)
+    shifts = rs.randint(0, m, B if per_item else 1)
+    mul = int(rs.choice([1, 3, 5, 7]))
+    f = lambda x, s: (mul * x + int(s)) % m
+    luts = np.stack([gen.GenLookUpTableExtended(lambda x, s=s: f(x, s)) for s in shifts])
+    msgs = rs.randint(0, m, B)
+    rng = o.rng(int(rs.randint(1, 2**31)))
+    cts = np.stack([o.encrypt_message(p, rng, int(x), m, K.s0) for x in msgs])
+    out = ctx.bootstrap_extended_batch(cts, luts if per_item else luts[0])
+    dec = np.array([o.decrypt_message(p, m, K.s0, np.ascontiguousarray(r)) for r in out])
+    want = np.array([f(int(x), shifts[i] if per_item else shifts[0]) for i, x in enumerate(msgs)])
+    bad = np.nonzero(dec != want)[0]
+    return bad.size == 0, f"{bad.size} of {B} items decrypt to the wrong entry (first: item {bad[0] if bad.size else -1})"
+
+
 def case_uint(rs, o, K, log):
     import torch
     p, ctx, m = K.p, K.ctx, UINT[K.name]
@@ -394,6 +419,10 @@ def run(seconds, seed, say, only_case=None):
                     ok, why = case_circuit(rs, o, key(name, n), log)
                 else:
                     ok, why = case_exact(rs, o, key(name, n), log)
+            elif rs.rand() < 0.25:
+                ext = int(rs.choice([2, 4, 9]))
+                name, n = ("uint5" if ext == 2 else "uint7"), (4 if ext == 9 else int(rs.choice([4, 12])))
+                ok, why = case_extended(rs, o, key(name, n), ext, log)
             else:
                 name, n = str(rs.choice(list(UINT))), int(rs.choice([4, 12]))
                 ok, why = case_uint(rs, o, key(name, n), log)
