@@ -544,3 +544,27 @@ def test_options_are_per_context_and_validated(pkg, keys_small):
         ctx.set_option("quad_max", q); ctx.set_option("oct_max", o); ctx.set_option("ks_mfma_min", m)
         assert np.array_equal(ctx.gate_batch("XOR", a, b), want), (q, o, m)
     ck.close()
+
+
+def test_device_pointer_batch_longer_than_a_slab_with_mux(oracle, keys_small, ck_small, pkg):
+    # tfhe_gate_batch_dev walks a batch in slabs of 65,536 items (fixed-size intermediate buffers); the MUX passes -- device-side
+    # compaction, two extra launches, scatter -- run per slab.  One call across the slab boundary with per-item ops incl. MUX, ragged
+    # second slab: the same words as the host-pointer path (which issues pieces of 16,384), and the oracle's on both sides of the boundary.
+    import torch
+    k = keys_small
+    n1 = k.p.n + 1
+    B = 65536 + 300
+    rs = np.random.RandomState(92)
+    a, b, c = (rand_u32(rs, (B, n1)) for _ in range(3))
+    ops = np.array([pkg.OPS[x] for x in ("NAND", "XOR", "MUX", "ANDNY", "MUX")], np.uint8)[rs.randint(0, 5, B)]
+    dev = lambda x: torch.from_numpy(x.view(np.int32)).cuda()
+    d_out = torch.empty((B, n1), dtype=torch.int32, device="cuda")
+    ck_small.ctx.gate_batch_dev(torch.from_numpy(ops).cuda(), dev(a), dev(b), dev(c), d_out)
+    ck_small.ctx.sync()
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, ck_small.ctx.gate_batch(ops, a, b, c))
+    sample = [0, 65535, 65536, 65537, B - 1] + [int(i) for i in np.where(ops == pkg.OPS["MUX"])[0][[0, -1]]]
+    ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops[sample], np.ascontiguousarray(a[sample]), np.ascontiguousarray(b[sample]),
+                               np.ascontiguousarray(c[sample]))
+    assert np.array_equal(got[sample], ref)
