@@ -282,3 +282,20 @@ def test_shim_calls_every_entry_point_with_the_declared_argument_count():
     assert len(calls) >= 15, sorted(calls)
     for other in ("shim/go/gates/gates_gpu.go", "shim/go/evaluator/evaluator_gpu.go"):
         assert 'import "C"' not in _read(other), f"{other} must not touch cgo: package gpu is the only cgo layer"
+
+
+def test_recorded_run_of_the_shims_own_go_test():
+    """shim/go/gates/gates_gpu_test.go -- what a Go user of the shim runs -- executed offline by the interpreter (cgo's C mocked on the oracle):
+    no failure in its three Test functions (every gate word for word against the reference's own), 60 gates through the C ABI, every context
+    the tests created released by their deferred gates.Release."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "goref", "shim_go_test_run.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/goref/shim_go_test_run.json not generated (make_goref_vectors.py --jobs shim_go_test)")
+    rec = json.load(open(path))
+    assert "NOT the Go toolchain" in rec["what"]
+    assert sorted(rec["tests"]) == ["TestBatchGates", "TestMUXNotCopyConstant", "TestScalarGatesTruthTablesAndWordParity"]
+    for name, t in rec["tests"].items():
+        assert t["failures"] == [] and not t["skipped"] and t["statements"] > 10**6, (name, t)
+    assert rec["c_abi_calls"]["gate_batch"] == 60 and rec["c_abi_calls"]["load_bsk"] == 3
+    assert rec["contexts_created"] == 9 and rec["contexts_alive_at_end"] == 0

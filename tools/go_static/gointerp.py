@@ -691,12 +691,13 @@ class Interp:
         self.ensure_init(pkg)
         return self.call_decl(pkg.funcs[func], pkg, list(args), None)
 
-    def run_reference_tests(self, pkg_name, only=None):
+    def run_reference_tests(self, pkg_name, only=None, pkg=None, directory=None):
         """Runs the reference's own Test* functions of one package (its *_test.go files: `package x` tests join the package, `package
         x_test` tests become a package of their own that imports it) with a testing.T stand-in.  Returns {test name: {"failures": [...],
         "skipped": bool, "statements": n}}; a test that panics is reported as a failure with the panic's message."""
-        pkg = self.load(pkg_name)
-        d = os.path.join(self.root, pkg_name)
+        # (pkg, directory: a package that does not live under the reference root -- the shim's own Go test, shim/go/gates)
+        pkg = pkg or self.load(pkg_name)
+        d = directory or os.path.join(self.root, pkg_name)
         ext = None
         loaded = getattr(pkg, "_tests_loaded", False)
         if not loaded:

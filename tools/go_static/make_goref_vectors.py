@@ -546,6 +546,31 @@ def job_reference_examples(_):
     print("[goref] wrote tests/golden/goref/reference_examples.json", flush=True)
 
 
+def job_shim_go_test(_):
+    """shim/go/gates/gates_gpu_test.go -- the Go test a user of the shim is asked to run -- EXECUTED by the interpreter: the shim and the
+    reference in one interpreter, cgo's "C" mocked on the oracle (tools/go_static/cmock.py), LWE dimension 1.  Its three Test functions
+    compare every gate of the shim WORD FOR WORD with the reference's own and must report no failure."""
+    import cmock
+    MOD = "github.com/thedonutfactory/go-tfhe-gpu"
+    I = gi.Interp(REF, seed=0x7F4E00F7)
+    I.extra_roots = {MOD: os.path.join(ROOT, "shim", "go")}
+    params = I.load("params")
+    I.pkg_value(params, "params128Bit").f["TLWELv0"].f["N"] = 1
+    mock = cmock.MockC(I, oracle(), device_count=2)
+    pkg = I.pkg_by_import(f"{MOD}/gates")
+    t0 = time.time()
+    res = I.run_reference_tests("gates", pkg=pkg, directory=os.path.join(ROOT, "shim", "go", "gates"))
+    calls = [c[0] for c in mock.calls]
+    out = {"what": "shim/go/gates/gates_gpu_test.go executed by tools/go_static/gointerp.py (NOT the Go toolchain) with cgo's C mocked on the CPU oracle, "
+                   "LWE dimension 1", "seconds": round(time.time() - t0), "tests": res, "c_abi_calls": {k: calls.count(k) for k in sorted(set(calls))},
+           "contexts_created": len(mock.ctxs), "contexts_alive_at_end": sum(c is not None for c in mock.ctxs)}   # `defer gates.Release(ck)` ran
+    for k, v in res.items():
+        print(f"[goref] {k}: failures {v['failures']} ({v['statements']} statements)", flush=True)
+    with open(os.path.join(OUT, "shim_go_test_run.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(f"[goref] wrote tests/golden/goref/shim_go_test_run.json ({time.time() - t0:.0f} s); calls {out['c_abi_calls']}", flush=True)
+
+
 def job_go_golden_program(_):
     """tools/go_golden/main.go -- the program that pins parity the day someone runs it with the Go toolchain -- EXECUTED by the interpreter
     (os / flag / encoding/binary stand-ins; the LWE dimension of both parameter sets set to 2 so that cloudkey.NewCloudKey is minutes, not
@@ -737,7 +762,7 @@ def job_full(spec):
 SMALL = {"fft": job_fft, "decompose_rotate": job_decompose_rotate, "extprod_chain": job_extprod_chain, "lut": job_lut,
          "small_bootstrap": job_small_bootstrap, "refkeygen": job_refkeygen, "reference_tests": job_reference_tests, "other_shapes": job_other_shapes,
          "go_golden_program": job_go_golden_program, "extract_keyswitch": job_extract_keyswitch,
-              "reference_tests_uint": job_reference_tests_uint, "reference_examples": job_reference_examples}
+              "reference_tests_uint": job_reference_tests_uint, "reference_examples": job_reference_examples, "shim_go_test": job_shim_go_test}
 FULL = [("boot", 0), ("boot", 1)] + [("gate", g) for g in ("NAND", "AND", "OR", "XOR", "XNOR", "NOR", "ANDNY", "ANDYN", "ORNY", "ORYN", "MUX")] + \
        [("pbs", 0), ("pbs", 1), ("pbs", 2)] + [("ingest", (i, min(i + 100, 700))) for i in range(0, 700, 100)] + [("gate80", "NAND"), ("gate110", "XOR")] + \
        [("pbsu", ("uint1", 2)), ("pbsu", ("uint2", 4)), ("pbsu", ("uint3", 8)), ("pbsu", ("uint4", 16))]
