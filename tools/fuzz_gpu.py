@@ -181,7 +181,26 @@ def case_exact(rs, o, K, log):
         if rs.rand() < 0.3:
             tv[..., 0, :] = 0                    # a look-up table proper: A = 0 (lut/generator.go)
         want, _ = o.bootstrap_batch(p, K.bsk, K.ksk, cts, tv)
-        got = ctx.bootstrap_batch(cts, tv)
+        if rs.rand() < 0.4:
+            # the device-pointer entry points on a side stream: blind rotate and key switch as two enqueued calls, or the fused one
+            dev = lambda x: torch.from_numpy(x.view(np.int32)).cuda()
+            s = torch.cuda.Stream()
+            d_out = torch.empty((B, n1), dtype=torch.int32, device="cuda")
+            with torch.cuda.stream(s):
+                d_cts, d_tv = dev(cts), dev(tv)
+                if rs.rand() < 0.5:
+                    log.append("dev-two-calls")
+                    d_acc = torch.empty((B, 2, p.N), dtype=torch.int32, device="cuda")
+                    ctx.blind_rotate_batch_dev(d_cts, d_tv, d_acc, stream=s)
+                    ctx.extract_keyswitch_batch_dev(d_acc, d_out, stream=s)
+                else:
+                    log.append("dev-fused")
+                    ctx.bootstrap_batch_dev(d_cts, d_tv, d_out, stream=s)
+            s.synchronize()
+            ctx.sync()
+            got = d_out.cpu().numpy().view(np.uint32)
+        else:
+            got = ctx.bootstrap_batch(cts, tv)
         return np.array_equal(got, want), "bootstrap words differ"
     cts = edge_rows(rs, words(rs, (min(B, 600), n1)))
     nsteps = int(rs.choice([-1, 0, 1, p.n // 2]))
