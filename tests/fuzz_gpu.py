@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzer: libtfhe_hip.so against the C oracle, for as many minutes as asked.
 
-    python tools/fuzz_gpu.py --minutes 10 --seed 1 [--log gpurun_out/fuzz.txt]
+    python tests/fuzz_gpu.py --minutes 10 --seed 1 [--log gpurun_out/fuzz.txt]
 
 Every case draws a parameter set, a (reduced) LWE dimension, a batch size weighted towards the dispatch boundaries of
 the library (1, the CU count, the slab and chunk sizes, +-1 around each), the entry point (gates with one op / one op per
@@ -29,7 +29,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))           # this file lives in tests/: it is test infrastructure (it drives the oracle)
 
 import __graft_entry__ as graft  # noqa: E402
 
@@ -450,7 +450,7 @@ def run(seconds, seed, say, only_case=None):
             say(f"case {k}: set={name} n={n} {' '.join(log)} -> {'ok' if ok else 'MISMATCH: ' + why}")
             if not ok:
                 raise AssertionError(f"case {k} ({name}, n={n}, {' '.join(log)}): {why}; "
-                                     f"REPRO: python tools/fuzz_gpu.py --seed {seed} --case {k}")
+                                     f"REPRO: python tests/fuzz_gpu.py --seed {seed} --case {k}")
             k += 1
             if only_case is not None or time.time() - t0 > seconds:
                 break

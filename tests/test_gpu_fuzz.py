@@ -1,4 +1,4 @@
-"""A short run of the differential fuzzer (tools/fuzz_gpu.py) in the GPU tier: random parameter set, LWE dimension, batch size
+"""A short run of the differential fuzzer (tests/fuzz_gpu.py) in the GPU tier: random parameter set, LWE dimension, batch size
 around the dispatch boundaries, entry point (host / device pointers, gates / MUX / programmable bootstraps / blind rotate + key
 switch) and dispatch options, against the C oracle -- every word identical at the exact sets, decryption + phase at the Uint
 sets.  Long runs are under profiles/ (r05_n_fuzz_*.txt)."""
@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
