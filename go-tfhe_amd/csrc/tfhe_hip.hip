@@ -1829,6 +1829,15 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
         if (op_uniform < 0 || op_uniform > TFHE_OP_MUX) return fail(TFHE_E_INVALID, "bad op code %d", op_uniform);
         if (op_uniform == TFHE_OP_MUX && !cc) return fail(TFHE_E_INVALID, "MUX needs the third operand");
     }
+#ifdef TFHE_FUZZ_CONTROL
+    // tests/fuzz_gpu.py's positive control (tools/build_variant_main.sh fuzzcontrol -DTFHE_FUZZ_CONTROL): ONE wrong bit in the last row of
+    // a batch of exactly one more than the CU count -- the kind of dispatch-boundary defect the fuzzer's batch sizes are weighted to find
+    if (B == c->num_cus + 1) {
+        rc = gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
+        out[(size_t)(B - 1) * ((size_t)c->P.n + 1)] ^= 1u;
+        return rc;
+    }
+#endif
     if (B > c->combine_max || B > combine_cap(c, 0)) return gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
     tfhe_ctx::GateReq me{0, ops, op_uniform, a, b, cc, out, B};
     return combine_request(c, me);
