@@ -397,3 +397,17 @@ def test_print_capture_and_format_verbs():
     pkg = I.load_source("main", {"x.go": src}, path="example.com/x")
     I.call_decl(pkg.funcs["main"], pkg, [], None)
     assert I.stdout == ["  7|0101|true|ab   |   cd|1.50\n", "✅ 3 false"]
+
+
+def test_shift_division_and_conversion_edge_cases_follow_go():
+    # shifts by >= the operand's width give 0 (or the sign for signed operands) in Go -- numpy's are undefined there; integer division and
+    # remainder truncate towards zero; float -> integer conversion truncates; int64 -> uint32 wraps (utils.F64ToTorus relies on the last two)
+    import gointerp as gi
+    I = gi.Interp(ROOT, seed=1)
+    I.stdout = []
+    src = ('package main\nimport "fmt"\nfunc main() {\n\tvar x uint32 = 0xDEADBEEF\n\tvar s uint = 32\n\tvar t uint = 40\n'
+           '\tfmt.Println(x>>s, x<<s, x>>t, x>>31, int32(x)>>31, int32(x)>>s)\n\tvar y int64 = -7\n\tfmt.Println(y/2, y%2, y>>1, uint8(300&0xFF))\n'
+           '\tvar u uint64 = 1<<63\n\tfmt.Println(u>>63, uint32(u>>40))\n\tf := -2.5\n\tfmt.Println(int(f), int64(f), uint32(int64(f)))\n}\n')
+    pkg = I.load_source("main", {"x.go": src}, path="example.com/x")
+    I.call_decl(pkg.funcs["main"], pkg, [], None)
+    assert I.stdout == ["0 0 0 1 -1 -1", "-3 -1 -4 44", "1 8388608", "-2 -2 4294967294"]
