@@ -55,6 +55,12 @@ def load_library():
     lib = C.CDLL(LIB_PATH)
     u32p, u8p, f64p, vp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.c_void_p
     lib.tfhe_last_error.restype = C.c_char_p
+    if hasattr(lib, "tfhe_build_flavor"):
+        lib.tfhe_build_flavor.restype = C.c_char_p
+        flavor = lib.tfhe_build_flavor().decode()
+        if flavor != "release" and not os.environ.get("TFHE_ALLOW_CONTROL_BUILD"):
+            raise TfheError(-1, f"{LIB_PATH} is a '{flavor}' build (a test-only variant that misbehaves on purpose); "
+                                "set TFHE_ALLOW_CONTROL_BUILD=1 only in the test that needs it")
     sig = {
         "tfhe_device_count": [C.POINTER(C.c_int)],
         "tfhe_ctx_create": [C.POINTER(Params), C.c_int, C.POINTER(vp)],
@@ -84,6 +90,11 @@ def load_library():
         "tfhe_blind_rotate_batch_dev": [vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp],
         "tfhe_external_product_batch": [vp, C.c_int, u32p, u32p, C.c_int],
         "tfhe_extract_keyswitch_batch": [vp, u32p, u32p, C.c_int],
+        "tfhe_ctx_decomposition_offset": [vp, u32p],
+        "tfhe_external_product_with": [vp, f64p, C.c_uint32, u32p, u32p, C.c_int],
+        "tfhe_cmux_with": [vp, f64p, C.c_uint32, u32p, u32p, u32p, C.c_int],
+        "tfhe_sample_extract_batch": [vp, u32p, C.c_int, u32p, C.c_int],
+        "tfhe_keyswitch_batch": [vp, u32p, u32p, C.c_int],
         "tfhe_extract_keyswitch_batch_dev": [vp, vp, vp, C.c_int, vp],
         "tfhe_gate_batch": [vp, u8p, C.c_int, u32p, u32p, u32p, u32p, C.c_int],
         "tfhe_gate_batch_dev": [vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp],
@@ -297,6 +308,67 @@ class Context:
         self._check(self._lib.tfhe_external_product_batch(self._h, int(key_index), _p32(trlwe), _p32(out), B))
         return out
 
+    def decomposition_offset(self):
+        """CloudKey.DecompositionOffset (cloudkey.go:60-71) as the context derived it."""
+        v = C.c_uint32(0)
+        self._check(self._lib.tfhe_ctx_decomposition_offset(self._h, C.byref(v)))
+        return int(v.value)
+
+    def _trgsw(self, trgsw):
+        p = self.params
+        g = np.ascontiguousarray(trgsw, dtype=np.float64)
+        if g.size != 2 * p.L * 2 * p.N:
+            raise ValueError(f"TRGSW operand holds {g.size} doubles, expected [2L][2][N] = {2 * p.L * 2 * p.N}")
+        return g
+
+    def external_product_with(self, trgsw, trlwe, offset=None):
+        """trgsw.ExternalProductWithFFT / Evaluator.ExternalProductAssign with any TRGSW operand ([2L][2][N] float64, reference layout)."""
+        p = self.params
+        g = self._trgsw(trgsw)
+        trlwe = _u32(trlwe)
+        B = trlwe.shape[0]
+        if trlwe.shape != (B, 2, p.N):
+            raise ValueError(f"trlwe shape {trlwe.shape}")
+        out = np.empty_like(trlwe)
+        off = self.decomposition_offset() if offset is None else int(offset)
+        self._check(self._lib.tfhe_external_product_with(self._h, g.ctypes.data_as(C.POINTER(C.c_double)), off, _p32(trlwe), _p32(out), B))
+        return out
+
+    def cmux_with(self, trgsw, ct0, ct1, offset=None):
+        """Evaluator.CMuxAssign(ctCond, ct0, ct1): ct0 + cond (x) (ct1 - ct0)."""
+        p = self.params
+        g = self._trgsw(trgsw)
+        ct0, ct1 = _u32(ct0), _u32(ct1)
+        B = ct0.shape[0]
+        if ct0.shape != (B, 2, p.N) or ct1.shape != ct0.shape:
+            raise ValueError(f"trlwe shapes {ct0.shape} / {ct1.shape}")
+        out = np.empty_like(ct0)
+        off = self.decomposition_offset() if offset is None else int(offset)
+        self._check(self._lib.tfhe_cmux_with(self._h, g.ctypes.data_as(C.POINTER(C.c_double)), off, _p32(ct0), _p32(ct1), _p32(out), B))
+        return out
+
+    def sample_extract_batch(self, trlwe, k=0):
+        """trlwe.SampleExtractIndex for any index k: [B][2][N] -> [B][N+1]."""
+        p = self.params
+        trlwe = _u32(trlwe)
+        B = trlwe.shape[0]
+        if trlwe.shape != (B, 2, p.N):
+            raise ValueError(f"trlwe shape {trlwe.shape}")
+        out = np.empty((B, p.N + 1), np.uint32)
+        self._check(self._lib.tfhe_sample_extract_batch(self._h, _p32(trlwe), int(k), _p32(out), B))
+        return out
+
+    def keyswitch_batch(self, lwe1):
+        """trgsw.IdentityKeySwitching on extracted samples: [B][N+1] -> [B][n+1]."""
+        p = self.params
+        lwe1 = _u32(lwe1)
+        B = lwe1.shape[0]
+        if lwe1.shape != (B, p.N + 1):
+            raise ValueError(f"TLWELv1 shape {lwe1.shape}")
+        out = np.empty((B, p.n + 1), np.uint32)
+        self._check(self._lib.tfhe_keyswitch_batch(self._h, _p32(lwe1), _p32(out), B))
+        return out
+
     def extract_keyswitch_batch(self, trlwe):
         p = self.params
         trlwe = _u32(trlwe)
@@ -429,7 +501,8 @@ class Context:
                                                   blob.numel() * blob.element_size(), self._stream(stream)))
 
     OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4, "combine_max": 5, "combine_launches": 6,
-               "combine_requests": 7, "ks_wide_ct": 8, "clone_path": 9, "clone_force_host": 10}
+               "combine_requests": 7, "ks_wide_ct": 8, "clone_path": 9, "clone_force_host": 10,
+               "combine_us_idle": 11, "combine_us_gather": 12, "combine_us_launch": 13}
     CLONE_PATHS = {0: "not a clone", 1: "same device (D2D)", 2: "peer copy (xGMI)", 3: "host-staged (no peer access)"}
 
     def set_option(self, name, value):

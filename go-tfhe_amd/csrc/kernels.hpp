@@ -897,6 +897,41 @@ static __global__ void k_scatter_rows(const uint32_t *__restrict__ src, const in
 }
 
 // ------------------------------------------------------------------------------------
+// Seam kernels of the trgsw / trlwe packages (SURVEY.md 8(b) seam 3): element-wise pieces around the external product and the
+// key switch, so that trgsw.CMUX, trlwe.SampleExtractIndex and trgsw.IdentityKeySwitching have entry points of their own.
+// ------------------------------------------------------------------------------------
+
+// out = a - b  (SUB = true: ct1 - ct0 of CMuxAssign, evaluator.go:93-96) or a + b (ct0 + product, evaluator.go:102-105), mod 2^32
+template <bool SUB>
+static __global__ void k_torus_addsub(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t *__restrict__ out, size_t words)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) out[i] = SUB ? a[i] - b[i] : a[i] + b[i];
+}
+
+// trlwe.SampleExtractIndexAssign for any index k (trlwe_ops.go:10-21): [B][2][N] -> [B][N+1], body last.
+static __global__ void k_sample_extract(const uint32_t *__restrict__ trlwe, uint32_t *__restrict__ out, int N, int k)
+{
+    const uint32_t *A = trlwe + (size_t)blockIdx.x * 2 * N, *Bp = A + N;
+    uint32_t *o = out + (size_t)blockIdx.x * (N + 1);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) o[i] = i <= k ? A[k - i] : ~A[N + k - i];
+    if (threadIdx.x == 0) o[N] = Bp[k];
+}
+
+// The TRLWE sample whose extraction at index 0 is a given TLWELv1 (the inverse of the above at k = 0; ~ is an involution, so this is
+// exact): lets trgsw.IdentityKeySwitching (keyswitch.go:10-37, input = an extracted sample) run on the fused extract + key-switch
+// kernels.  [B][N+1] -> [B][2][N]; only B[0] of the body polynomial is ever read by the key switch, the rest is zeroed.
+static __global__ void k_unextract(const uint32_t *__restrict__ lwe1, uint32_t *__restrict__ trlwe, int N)
+{
+    const uint32_t *p = lwe1 + (size_t)blockIdx.x * (N + 1);
+    uint32_t *A = trlwe + (size_t)blockIdx.x * 2 * N, *Bp = A + N;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        A[i] = i == 0 ? p[0] : ~p[N - i];
+        Bp[i] = i == 0 ? p[N] : 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Device-side MUX split (gates.go:107-114): the compact, ascending list of the items whose op code is MUX,
 // built without the host ever seeing the op codes.  Three launches: per-block counts, one-block scan, fill.
 // ------------------------------------------------------------------------------------

@@ -111,8 +111,9 @@ struct tfhe_ctx {
     // pointing at freed memory.  From then on a call that needs larger buffers fails with TFHE_E_INVALID instead
     // (tfhe_ctx_reserve before capturing; TFHE_OPT_FROZEN = 0 once the graphs are gone).
     bool frozen = false;
-    int oct_limit = 0;          // ... and of up to this many the eight-wave kernel (one bootstrap per CU)
-    int quad_limit = 0;         // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
+    // read lock-free by combine_cap (tfhe_gate_batch / tfhe_bootstrap_batch before they take any lock): atomics
+    std::atomic<int> oct_limit{0};      // ... and of up to this many the eight-wave kernel (one bootstrap per CU)
+    std::atomic<int> quad_limit{0};     // launches of up to this many bootstraps use the four-wave kernel (N = 1024 shapes)
     hipStream_t stream = nullptr;
     hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     bool ev_valid[2] = {false, false};
@@ -131,29 +132,48 @@ struct tfhe_ctx {
     std::atomic<bool> have_bsk{false}, have_ksk{false};
     // staging (grow-only)
     DevBuf s_in0, s_in1, s_in2, s_out, s_trlwe, s_tv, s_ops, s_idx, s_plan, s_t0, s_t1, s_t2, s_t3;
+    DevBuf s_gsw_raw, s_gsw;    // one caller-supplied TRGSW operand (tfhe_external_product_with / tfhe_cmux_with): reference layout, wave-native layout
     std::recursive_mutex mu;    // host-pointer calls hold it for their whole duration, _dev calls while they reserve and enqueue
-    // Flat combining of concurrent host-pointer callers (combine_request below): requests that arrive while a launch is in flight
-    // queue here, and the next leader issues ALL of them as one batch.  One queue per kind of request -- gate batches
-    // (tfhe_gate_batch) and programmable bootstraps (tfhe_bootstrap_batch) -- because a launch carries one kind.
+    // Flat combining of concurrent host-pointer callers (combine_request below).  One queue per kind of request -- gate batches
+    // (tfhe_gate_batch) and programmable bootstraps (tfhe_bootstrap_batch) -- because a launch carries one kind.  Every queue is a ring
+    // of three BATCHES: one accepting requests (callers claim rows of its page-locked staging with a compare-and-swap and copy their
+    // operands in themselves), one whose launch is in flight, one whose callers are taking their rows out.
     struct GateReq {
         int kind;                       // 0: gates (ops / op_uniform, a, b, cc), 1: bootstraps through a table (a = in, b = tv, op_uniform = tv_per_item)
         const uint8_t *ops; int op_uniform; const uint32_t *a, *b, *cc; uint32_t *out; int B;
+        int pos = 0;                    // first row of this request in its batch's staging
         int rc = TFHE_OK; std::string err;
-        std::atomic<int> state{0};      // 0 waiting, 1 done (rc / err are final), 2 promoted to leader
+    };
+    struct CombBatch {
+        static constexpr uint64_t kClosed = 1ull << 31;
+        // rows claimed so far (bits 0-30), closed flag (bit 31), bootstraps those rows stand for (bits 32-63: a MUX row is two, see combine_weight)
+        std::atomic<uint64_t> claim{kClosed};
+        std::atomic<int> filled{0};     // rows whose operands are in staging and whose request is registered
+        std::atomic<int> nreq{0};
+        std::atomic<uint32_t> done{1};  // futex word: 0 from the moment the batch opens until its results (or errors) are final
+        std::atomic<int> readers{0};    // followers that have yet to take their rows out: the slot is not re-opened before that
+        std::atomic<bool> any_c{false}, full{false};
+        std::vector<GateReq *> reqs;    // [cap_rows], fixed at allocation
+        char *host = nullptr;           // page-locked: gates [a | b | c | out][cap_rows][n+1] + [cap_rows] op codes; bootstraps [in | out][cap_rows][n+1] + [cap_rows][2][N]
     };
     struct CombQueue {
-        std::mutex mu;
-        std::atomic<uint32_t> gen{0};   // bumped behind every launch; waiters sleep on it (futex): ONE wake-all per launch
-        std::deque<GateReq *> pending;
-        bool leader = false;            // some thread is executing (or about to execute) combined launches
-        size_t last_batch = 0;          // requests the most recent launch carried (the gathering wait's target)
-        std::chrono::steady_clock::time_point last_done{};   // ... and when it finished
+        CombBatch ring[3];
+        std::atomic<int> open{0};               // the batch that accepts requests
+        std::atomic<uint32_t> open_gen{0};      // futex word: bumped whenever `open` moves (callers that found the batch closed or full sleep here)
+        std::atomic<int> returning{0};          // requests of the most recent launch that have not been seen again yet (the gathering wait's target)
+        std::atomic<uint32_t> gather{0};        // futex word the gathering leader sleeps on
+        std::atomic<long long> last_done_ns{0}; // steady clock, when the most recent launch finished
+        std::atomic<bool> ready{false};         // staging allocated (by the first caller that is about to FOLLOW: a lone caller never needs it)
+        std::mutex alloc_mu;
+        int cap_rows = 0;
     };
     CombQueue comb[2];
     std::atomic<int> combine_max{0};        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
-    void *comb_host = nullptr;  // page-locked staging of one combined launch: [a | b | c | out][rows][n+1] + op codes
-    size_t comb_host_cap = 0;
     std::atomic<long long> comb_launches{0}, comb_requests{0};     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
+    // where the time between two combined launches goes (TFHE_OPT_COMBINE_US_*; nanoseconds, summed over the combined launches):
+    // idle = previous launch done -> this one issued; gather = the part of it the leader spent waiting for returning callers;
+    // launch = transfers + kernels + synchronisation
+    std::atomic<long long> comb_ns_idle{0}, comb_ns_gather{0}, comb_ns_launch{0};
     std::vector<uint32_t> gate_tv_host;                 // the gate test vector (a combined bootstrap launch carries one table per item)
     void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
                                                         // reads them after the call has returned
@@ -822,61 +842,6 @@ int gate_batch_serial(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uin
     return TFHE_OK;
 }
 
-int comb_staging(tfhe_ctx *c, size_t need);       // page-locked staging of the combined launches (below)
-
-// One launch for the requests of several callers: their rows are packed behind one another in page-locked staging
-// (one host copy per operand and request, ONE transfer per operand plane), every item carries its own op code, and
-// each caller gets its rows back.  A gate's result depends on its own operands only -- not on its position in a batch,
-// not on the batch's size or kernel shape (tests: batch-position invariance) -- so every caller receives exactly the
-// words the serial path would have given it.
-int run_combined(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
-{
-    int rc;
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    const size_t n1 = (size_t)c->P.n + 1;
-    size_t total = 0;
-    bool any_c = false;
-    for (auto *r : batch) { total += (size_t)r->B; any_c = any_c || r->cc; }
-    const size_t plane = total * n1 * 4, planes = any_c ? 4 : 3;          // a, b, [c], out
-    const size_t need = planes * plane + total;
-    if ((rc = comb_staging(c, need))) return rc;
-    char *ha = static_cast<char *>(c->comb_host), *hb = ha + plane, *hc = any_c ? hb + plane : nullptr;
-    char *ho = ha + (planes - 1) * plane;
-    uint8_t *hops = reinterpret_cast<uint8_t *>(ha + planes * plane);
-    size_t at = 0;
-    for (auto *r : batch) {
-        const size_t bytes = (size_t)r->B * n1 * 4;
-        memcpy(ha + at * n1 * 4, r->a, bytes);
-        memcpy(hb + at * n1 * 4, r->b, bytes);
-        if (hc) {
-            if (r->cc) memcpy(hc + at * n1 * 4, r->cc, bytes);
-            else memset(hc + at * n1 * 4, 0, bytes);                      // never read: none of this request's ops is MUX
-        }
-        if (r->ops) memcpy(hops + at, r->ops, (size_t)r->B);
-        else memset(hops + at, r->op_uniform, (size_t)r->B);
-        at += (size_t)r->B;
-    }
-    if ((rc = c->s_in0.reserve(plane)) || (rc = c->s_in1.reserve(plane)) || (rc = c->s_out.reserve(plane))) return rc;
-    if (any_c && (rc = c->s_in2.reserve(plane))) return rc;
-    if ((rc = c->s_ops.reserve(total))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->s_in0.p, ha, plane, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->s_in1.p, hb, plane, hipMemcpyHostToDevice, c->stream));
-    if (any_c) HIP_TRY(hipMemcpyAsync(c->s_in2.p, hc, plane, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->s_ops.p, hops, total, hipMemcpyHostToDevice, c->stream));
-    if ((rc = gate_batch_device(c, c->s_ops.as<uint8_t>(), 0, c->s_in0.as<uint32_t>(), c->s_in1.as<uint32_t>(),
-                                any_c ? c->s_in2.as<uint32_t>() : nullptr, c->s_out.as<uint32_t>(), (int)total, c->stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(ho, c->s_out.p, plane, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    at = 0;
-    for (auto *r : batch) {
-        memcpy(r->out, ho + at * n1 * 4, (size_t)r->B * n1 * 4);
-        at += (size_t)r->B;
-    }
-    c->comb_launches++;
-    c->comb_requests += (long long)batch.size();
-    return TFHE_OK;
-}
-
 // The host-pointer programmable bootstrap of ONE caller (evaluator.BootstrapLUT, programmable_bootstrap.go:93-115).
 int bootstrap_batch_serial(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out, int B)
 {
@@ -894,86 +859,170 @@ int bootstrap_batch_serial(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, 
     return TFHE_OK;
 }
 
-int comb_staging(tfhe_ctx *c, size_t need)
-{
-    if (need <= c->comb_host_cap) return TFHE_OK;
-    if (c->comb_host) (void)hipHostFree(c->comb_host);
-    c->comb_host = nullptr; c->comb_host_cap = 0;
-    const size_t cap = need < ((size_t)1 << 22) ? ((size_t)1 << 22) : need + need / 2;
-    hipError_t e = hipHostMalloc(&c->comb_host, cap, hipHostMallocDefault);
-    if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-    c->comb_host_cap = cap;
-    return TFHE_OK;
-}
-
-// One launch for the programmable bootstraps of several callers: rows packed as in run_combined, ONE TABLE PER ITEM (each
-// caller's table -- its own per-item tables, or its one table repeated, or the gate test vector where it passed none).  An
-// item's result depends on its own sample and table only, and the launch stays within the kernel shape a call on its own
-// would have run (combine_cap), so every caller receives exactly the words the serial path would have given it.
-int run_combined_pbs(tfhe_ctx *c, std::vector<tfhe_ctx::GateReq *> &batch)
-{
-    int rc;
-    std::lock_guard<std::recursive_mutex> lk(c->mu);
-    const size_t n1 = (size_t)c->P.n + 1, tw = (size_t)2 * c->P.N;
-    size_t total = 0;
-    for (auto *r : batch) total += (size_t)r->B;
-    const size_t rows = total * n1 * 4, tabs = total * tw * 4;
-    if ((rc = comb_staging(c, 2 * rows + tabs))) return rc;
-    char *hin = static_cast<char *>(c->comb_host), *hout = hin + rows, *htv = hout + rows;
-    size_t at = 0;
-    for (auto *r : batch) {
-        memcpy(hin + at * n1 * 4, r->a, (size_t)r->B * n1 * 4);
-        const uint32_t *tv = r->b ? r->b : c->gate_tv_host.data();
-        if (r->b && r->op_uniform) memcpy(htv + at * tw * 4, tv, (size_t)r->B * tw * 4);
-        else for (int k = 0; k < r->B; k++) memcpy(htv + (at + (size_t)k) * tw * 4, tv, tw * 4);
-        at += (size_t)r->B;
-    }
-    if ((rc = c->s_in0.reserve(rows)) || (rc = c->s_out.reserve(rows)) || (rc = c->s_tv.reserve(tabs))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->s_in0.p, hin, rows, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->s_tv.p, htv, tabs, hipMemcpyHostToDevice, c->stream));
-    if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), c->s_tv.as<uint32_t>(), 1, c->s_out.as<uint32_t>(), (int)total, c->stream)))
-        return rc;
-    HIP_TRY(hipMemcpyAsync(hout, c->s_out.p, rows, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    at = 0;
-    for (auto *r : batch) {
-        memcpy(r->out, hout + at * n1 * 4, (size_t)r->B * n1 * 4);
-        at += (size_t)r->B;
-    }
-    c->comb_launches++;
-    c->comb_requests += (long long)batch.size();
-    return TFHE_OK;
-}
-
-// Items one combined launch may carry.  At the N = 1024, L = 3, Bgbit = 6 shape (80 / 110 / 128-bit sets) every transform is
-// exact: whatever kernel runs an item, its words are the same, so a launch may be as long as the pipelined
-// host path allows.  At every other shape (tolerance regime) the kernels of different launch shapes round differently -- gates
-// included: the gate test vector goes through the same transforms -- so a combined launch stays within the kernel shape a lone
-// small call runs: at most one bootstrap per CU AND within the four-/eight-wave limits of the context (TFHE_OPT_QUAD_MAX /
-// TFHE_OPT_OCT_MAX overrides move those).  Requests longer than the cap are not combined at all.
+// Items one combined launch may carry, in BOOTSTRAPS.  At the N = 1024, L = 3, Bgbit = 6 shape (80 / 110 / 128-bit sets) every
+// transform is exact: whatever kernel runs an item, its words are the same, so a launch may be as long as its
+// staging (one full launch's worth of rows).  At every other shape (tolerance regime) the kernels of different launch shapes round
+// differently -- gates included: the gate test vector goes through the same transforms -- so a combined launch stays within the kernel
+// shape a lone small call runs: at most one bootstrap per CU AND within the four-/eight-wave limits of the context (TFHE_OPT_QUAD_MAX /
+// TFHE_OPT_OCT_MAX overrides move those).  Requests heavier than the cap are not combined at all.
 int combine_cap(const tfhe_ctx *c, int kind)
 {
     (void)kind;
-    if (c->shape == kShapeN1024_L3_B6) return pipe_items(c);
+    if (c->shape == kShapeN1024_L3_B6) return 2 * launch_items(c);       // rows are bounded by the staging (launch_items); a MUX row is two bootstraps
     int cap = c->num_cus;
     if (shape_is_1024(c->shape)) {              // the small-launch kernels exist at the N = 1024 shapes only
-        if (c->quad_limit > 0 && c->quad_limit < cap) cap = c->quad_limit;
-        if (c->oct_limit > 0 && c->oct_limit < cap) cap = c->oct_limit;
+        const int q = c->quad_limit.load(), o = c->oct_limit.load();
+        if (q > 0 && q < cap) cap = q;
+        if (o > 0 && o < cap) cap = o;
     }
     return cap < 1 ? 1 : cap;
 }
 
-// Flat combining (the reference's concurrency is goroutine fan-out over pooled evaluators, trgsw.go:227-252; its scalar
-// gates.* serialise on one evaluator, gates.go:19-23,136-142).  A launch of 1 ... 256 bootstraps costs the same 2.4 ms, so N
-// threads issuing scalar gates one launch each would get N x 2.4 ms.  Instead: a caller that finds no launch in flight
-// becomes the LEADER and issues its request at once (a lone caller's latency is unchanged: its request is launched as it
-// always was); callers that arrive meanwhile queue; when the leader's launch is done it hands leadership to the oldest
-// waiter, which issues EVERYTHING queued (of its kind: gates, or bootstraps through a table) as one batch and distributes the rows.  No extra thread; the only waiting is a
-// bounded gathering wait (<= ~200 us) of a leader that takes over right behind a combined launch, so that the callers that launch
-// carried -- who are waking up at that moment -- travel together again instead of one by one or in two alternating cohorts.
-// Waiters sleep on ONE generation word (futex) that every finished launch bumps and wakes: one system call for all of them,
-// no mutex on the wake path.  256 threads x 40 dependent scalar gates: 25 s serialised -> 0.124 s; 256 threads x 8 dependent Uint5
-// bootstraps through their own tables: 8.4 s -> 67 ms (profiles/r04_d_combine.txt).
+// Bootstraps of the widest blind-rotate request a gate call puts into a launch: a row that may be a MUX adds its ANDNY(a, c) to pass 1
+// (gate_batch_device: S + Mx items), so it weighs two (counting rows let 200 single-MUX callers form a 400-bootstrap
+// launch -- a different kernel shape than the lone call's).
+int combine_weight(const tfhe_ctx::GateReq &r)
+{
+    const bool may_mux = r.kind == 0 && r.cc && (r.ops || r.op_uniform == TFHE_OP_MUX);
+    return may_mux ? 2 * r.B : r.B;
+}
+
+int combine_rows(const tfhe_ctx *c, int kind)
+{
+    const int cap = combine_cap(c, kind), li = launch_items(c);
+    return cap < li ? cap : li;
+}
+
+long long steady_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void futex_wait(std::atomic<uint32_t> &w, uint32_t seen, long timeout_us = 0)
+{
+    struct timespec ts{0, timeout_us * 1000};
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&w), FUTEX_WAIT_PRIVATE, seen, timeout_us ? &ts : nullptr, nullptr, 0);
+}
+
+void futex_wake_all(std::atomic<uint32_t> &w)
+{
+    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&w), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+
+// Page-locked staging of the three batches of a queue, allocated by the first caller that is about to FOLLOW another one (a context
+// that only ever sees lone callers never allocates it).  Sized for the parameter shape's largest combined launch (combine_rows at
+// the default limits: set_option may only lower the bootstraps per launch afterwards, never the row capacity).
+int comb_ensure_staging(tfhe_ctx *c, int kind)
+{
+    tfhe_ctx::CombQueue &Q = c->comb[kind];
+    if (Q.ready.load(std::memory_order_acquire)) return TFHE_OK;
+    std::lock_guard<std::mutex> lk(Q.alloc_mu);
+    if (Q.ready.load(std::memory_order_relaxed)) return TFHE_OK;
+    const size_t rows = (size_t)Q.cap_rows, n1 = (size_t)c->P.n + 1;
+    const size_t bytes = kind == 0 ? 4 * rows * n1 * 4 + rows : 2 * rows * n1 * 4 + rows * 2 * c->P.N * 4;
+    try {
+        for (auto &b : Q.ring) b.reqs.assign(rows, nullptr);
+    } catch (...) {
+        return fail(TFHE_E_NOMEM, "out of host memory for the combining queue");
+    }
+    for (auto &b : Q.ring) {
+        if (b.host) continue;
+        void *h = nullptr;
+        hipError_t e = hipHostMalloc(&h, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(TFHE_E_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        b.host = static_cast<char *>(h);
+    }
+    Q.ready.store(true, std::memory_order_release);
+    return TFHE_OK;
+}
+
+struct CombPlanes {                 // where a batch's planes live in its staging
+    char *a, *b, *c, *out, *tv;
+    uint8_t *ops;
+};
+CombPlanes comb_planes(const tfhe_ctx *c, const tfhe_ctx::CombQueue &Q, const tfhe_ctx::CombBatch &bt, int kind)
+{
+    const size_t plane = (size_t)Q.cap_rows * ((size_t)c->P.n + 1) * 4;
+    CombPlanes p{};
+    p.a = bt.host;
+    if (kind == 0) {
+        p.b = p.a + plane; p.c = p.b + plane; p.out = p.c + plane;
+        p.ops = reinterpret_cast<uint8_t *>(p.out + plane);
+    } else {
+        p.out = p.a + plane; p.tv = p.out + plane;
+    }
+    return p;
+}
+
+// A caller's operands into its rows of the batch's staging (done by the caller itself: 256 callers copy in parallel while the
+// previous launch's other callers are still waking up, instead of one leader copying 256 requests in sequence).
+void comb_copy_in(const tfhe_ctx *c, const tfhe_ctx::CombQueue &Q, tfhe_ctx::CombBatch &bt, const tfhe_ctx::GateReq &r)
+{
+    const size_t n1b = ((size_t)c->P.n + 1) * 4, at = (size_t)r.pos, bytes = (size_t)r.B * n1b;
+    const CombPlanes p = comb_planes(c, Q, bt, r.kind);
+    memcpy(p.a + at * n1b, r.a, bytes);
+    if (r.kind == 0) {
+        memcpy(p.b + at * n1b, r.b, bytes);
+        if (r.cc) { memcpy(p.c + at * n1b, r.cc, bytes); bt.any_c.store(true, std::memory_order_relaxed); }
+        else memset(p.c + at * n1b, 0, bytes);                           // never read by the kernels (none of this request's ops is MUX); defined all the same
+        if (r.ops) memcpy(p.ops + at, r.ops, (size_t)r.B);
+        else memset(p.ops + at, r.op_uniform, (size_t)r.B);
+    } else {
+        const size_t twb = (size_t)2 * c->P.N * 4;
+        const uint32_t *tv = r.b ? r.b : c->gate_tv_host.data();
+        if (r.b && r.op_uniform) memcpy(p.tv + at * twb, tv, (size_t)r.B * twb);
+        else for (int k = 0; k < r.B; k++) memcpy(p.tv + (at + (size_t)k) * twb, tv, twb);
+    }
+}
+
+// ONE launch for the `rows` rows of a closed batch: one transfer per operand plane, every item with its own op code (gates) or its own
+// table (bootstraps), results into the staging's out plane.  A gate's (a bootstrap's) result depends on its own operands only -- not
+// on its position in a batch, nor, within the limits of combine_cap, on the batch's size -- so every caller receives exactly the words
+// the serial path would have given it (tests: batch-position invariance, combined == lone).
+int run_combined(tfhe_ctx *c, tfhe_ctx::CombQueue &Q, tfhe_ctx::CombBatch &bt, int kind, int rows)
+{
+    int rc;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t n1 = (size_t)c->P.n + 1, plane = (size_t)rows * n1 * 4;
+    const CombPlanes p = comb_planes(c, Q, bt, kind);
+    if (kind == 0) {
+        const bool any_c = bt.any_c.load(std::memory_order_relaxed);
+        if ((rc = c->s_in0.reserve(plane)) || (rc = c->s_in1.reserve(plane)) || (rc = c->s_out.reserve(plane))) return rc;
+        if (any_c && (rc = c->s_in2.reserve(plane))) return rc;
+        if ((rc = c->s_ops.reserve((size_t)rows))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->s_in0.p, p.a, plane, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->s_in1.p, p.b, plane, hipMemcpyHostToDevice, c->stream));
+        if (any_c) HIP_TRY(hipMemcpyAsync(c->s_in2.p, p.c, plane, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->s_ops.p, p.ops, (size_t)rows, hipMemcpyHostToDevice, c->stream));
+        if ((rc = gate_batch_device(c, c->s_ops.as<uint8_t>(), 0, c->s_in0.as<uint32_t>(), c->s_in1.as<uint32_t>(),
+                                    any_c ? c->s_in2.as<uint32_t>() : nullptr, c->s_out.as<uint32_t>(), rows, c->stream))) return rc;
+    } else {
+        const size_t tabs = (size_t)rows * 2 * c->P.N * 4;
+        if ((rc = c->s_in0.reserve(plane)) || (rc = c->s_out.reserve(plane)) || (rc = c->s_tv.reserve(tabs))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->s_in0.p, p.a, plane, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->s_tv.p, p.tv, tabs, hipMemcpyHostToDevice, c->stream));
+        if ((rc = bootstrap_device(c, c->s_in0.as<uint32_t>(), c->s_tv.as<uint32_t>(), 1, c->s_out.as<uint32_t>(), rows, c->stream))) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(p.out, c->s_out.p, plane, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+// Flat combining (the reference's concurrency is goroutine fan-out over pooled evaluators, trgsw.go:227-252; its scalar gates.* serialise
+// on one evaluator, gates.go:19-23,136-142).  A launch of 1 ... 256 bootstraps costs the same ~2.2 ms, so N threads issuing scalar gates
+// one launch each would take N x 2.2 ms.  Instead (round 6: lock-free, every caller moves its own rows):
+//   * a caller CLAIMS rows of the open batch's page-locked staging with one compare-and-swap -- no mutex: 255 callers coming back from
+//     a launch within ~150 us formed a convoy on the queue mutex -- copies its operands in itself and sleeps on that batch's `done` word;
+//   * the caller that claimed row 0 is the batch's LEADER.  It waits for the previous batch's launch, then for the callers that launch
+//     carried to come back (`returning`: every claim counts one down; the wait ends when it reaches zero, when nobody has arrived for
+//     150 us, when the batch is full, or after 600 us -- round 5 polled with 20 us sleeps for at most 200 us and compared against the
+//     PREVIOUS launch's size only, so two cohorts formed at thread start-up never merged and took turns: 49-53 launches for 40 rounds);
+//     closes the batch, opens the next one (arrivals from now on queue there), issues ONE launch, and wakes its followers through the
+//     batch's own futex word (one system call, 0.55 us per sleeper measured on the GPU box; tools/ubench_wake.cpp);
+//   * every follower takes its rows out of the staging itself; the slot is re-opened only after the last one has.
+// A lone caller claims row 0 of an empty batch, finds nothing to wait for and runs the serial path on its own pointers: a few atomic
+// operations more than round 5, no staging.  If a combined launch fails for a reason only the combination has (scratch a frozen context
+// may not grow, ...), its requests are re-issued one by one from the staging, each with its own result.
 #ifdef TFHE_TSAN_CONTROL
 long g_tsan_control;         // tools/asan_host_check.sh control thread: a deliberate unsynchronised counter the ThreadSanitizer build must report
 #endif
@@ -982,114 +1031,152 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
 #ifdef TFHE_TSAN_CONTROL
     g_tsan_control++;
 #endif
+    using Batch = tfhe_ctx::CombBatch;
     tfhe_ctx::CombQueue &Q = c->comb[me.kind];
-    std::unique_lock<std::mutex> lk(Q.mu);
-    Q.pending.push_back(&me);
-    bool gather;
-    if (Q.leader) {
-        // wait without the queue mutex: sleep on the generation word, which every finished launch bumps and wakes (one system
-        // call for all waiters); a waiter whose own request is not settled yet goes back to sleep on the new value
-        lk.unlock();
-        int st;
-        for (;;) {
-            const uint32_t gen = Q.gen.load(std::memory_order_acquire);
-            if ((st = me.state.load(std::memory_order_acquire)) != 0) break;
-            syscall(SYS_futex, reinterpret_cast<uint32_t *>(&Q.gen), FUTEX_WAIT_PRIVATE, gen, nullptr, nullptr, 0);
+    auto serial = [&](const tfhe_ctx::GateReq &r, const uint8_t *ops, const uint32_t *a, const uint32_t *b, const uint32_t *cc, uint32_t *out) {
+        return r.kind == 0 ? gate_batch_serial(c, ops, ops ? 0 : r.op_uniform, a, b, cc, out, r.B)
+                           : bootstrap_batch_serial(c, a, b, r.op_uniform, out, r.B);
+    };
+    const int w = combine_weight(me), cap_w = combine_cap(c, me.kind), cap_rows = Q.cap_rows;
+    if (w > cap_w || me.B > cap_rows) return serial(me, me.ops, me.a, me.b, me.cc, me.out);     // limits lowered since the caller's pre-check
+    // ---- claim rows of the open batch
+    int bi;
+    uint64_t cl;
+    for (;;) {
+        const uint32_t og = Q.open_gen.load(std::memory_order_acquire);
+        bi = Q.open.load(std::memory_order_acquire);
+        Batch &bt = Q.ring[bi];
+        cl = bt.claim.load(std::memory_order_acquire);
+        const int rows = (int)(cl & (Batch::kClosed - 1)), wsum = (int)(cl >> 32);
+        if ((cl & Batch::kClosed) || rows + me.B > cap_rows || wsum + w > cap_w) {
+            if (!(cl & Batch::kClosed) && !bt.full.exchange(true)) {            // full: its leader need not wait for anybody else
+                Q.gather.fetch_add(1, std::memory_order_release);
+                futex_wake_all(Q.gather);
+            }
+            futex_wait(Q.open_gen, og, 2000);                 // until the next batch opens (bounded: a missed wake-up costs 2 ms, never a hang)
+            continue;
         }
-        if (st == 1) {
-            if (me.rc) g_err = me.err;
-            return me.rc;
+        if (rows > 0) {                                       // about to follow somebody: the staging must exist
+            if (comb_ensure_staging(c, me.kind)) return serial(me, me.ops, me.a, me.b, me.cc, me.out);      // no page-locked memory: uncombined
         }
-        lk.lock();
-        gather = true;                                  // promoted under contention
-    } else {
-        Q.leader = true;
-        // a fresh leader right behind a combined launch is not a lone caller: it is the first of that launch's callers to be back
-        // (the queue was empty when the launch ended because the launch had carried everybody)
-        gather = Q.last_batch > 1 && std::chrono::steady_clock::now() - Q.last_done < std::chrono::microseconds(500);
+        if (bt.claim.compare_exchange_weak(cl, cl + (uint64_t)me.B + ((uint64_t)w << 32), std::memory_order_acq_rel)) break;
     }
-    if (gather) {
-        // The callers the previous launch carried are waking up this very moment and will be back with their next request within
-        // microseconds; launching without them makes two cohorts that take turns (each launch half as full as it could be at the same
-        // cost), or -- when the launch carried everybody -- a launch for the first one back alone.  Let them queue: re-check the queue
-        // until a DEADLINE of 200 us on the steady clock (8 % of the launch this wait precedes; a count of sleeps is not a bound: with
-        // the default 50 us timer slack ten 20 us sleeps take ~0.7 ms); stop as soon as the queue no longer grows, or as many callers
-        // are queued as the previous launch carried (in steady state: everybody is back).  A lone caller never gets here.
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(200);
-        size_t seen = Q.pending.size();
-        for (int still = 0; still < 2 && seen < Q.last_batch && std::chrono::steady_clock::now() < deadline;) {
-            lk.unlock();
-            std::this_thread::sleep_for(std::chrono::microseconds(20));
-            lk.lock();
-            still = Q.pending.size() == seen ? still + 1 : 0;
-            seen = Q.pending.size();
-        }
+    Batch &bt = Q.ring[bi];
+    me.pos = (int)(cl & (Batch::kClosed - 1));
+    if (Q.returning.load(std::memory_order_relaxed) > 0 && Q.returning.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        Q.gather.fetch_add(1, std::memory_order_release);     // the last caller of the previous launch is back: the gathering leader may go
+        futex_wake_all(Q.gather);
     }
-    // leader: `me` is the oldest pending request; take it and as many of the following as one launch may carry.  Nothing in the
-    // leader section may throw past this function (the ABI never throws, and every waiter of the batch sleeps until its request is
-    // settled): allocation failures are caught and settle the whole batch with TFHE_E_NOMEM.
-    std::vector<tfhe_ctx::GateReq *> batch;
-    int rc = TFHE_OK;
-    bool individually = false;      // every request of the batch already carries its own result
-    std::string err;
-    try {
-        const int cap = combine_cap(c, me.kind);
-        int total = 0;
-        batch.reserve(Q.pending.size());
-        while (!Q.pending.empty() && (batch.empty() || total + Q.pending.front()->B <= cap)) {
-            batch.push_back(Q.pending.front());
-            total += Q.pending.front()->B;
-            Q.pending.pop_front();
+    if (me.pos > 0) {
+        // ---- follower: operands in, sleep until the batch is done, rows out
+        comb_copy_in(c, Q, bt, me);
+        bt.reqs[(size_t)bt.nreq.fetch_add(1, std::memory_order_acq_rel)] = &me;
+        bt.filled.fetch_add(me.B, std::memory_order_release);
+        while (bt.done.load(std::memory_order_acquire) == 0) futex_wait(bt.done, 0);
+        const int rc = me.rc;
+        if (rc) g_err = me.err;
+        else {
+            const size_t n1b = ((size_t)c->P.n + 1) * 4;
+            memcpy(me.out, comb_planes(c, Q, bt, me.kind).out + (size_t)me.pos * n1b, (size_t)me.B * n1b);
         }
-        Q.last_batch = batch.size();
-        lk.unlock();
-        auto serial = [&](tfhe_ctx::GateReq &r) {
-            return r.kind == 0 ? gate_batch_serial(c, r.ops, r.op_uniform, r.a, r.b, r.cc, r.out, r.B)
-                               : bootstrap_batch_serial(c, r.a, r.b, r.op_uniform, r.out, r.B);
-        };
-        if (batch.size() == 1) {
-            rc = serial(me);
-            if (rc) err = g_err;
+        bt.readers.fetch_sub(1, std::memory_order_release);   // nothing of the batch is touched after this
+        return rc;
+    }
+    // ---- leader of batch bi.  Nothing here may throw past this function (the ABI never throws, and every follower sleeps until the
+    // batch is settled): the only allocations are error strings, guarded below.
+    Batch &prev = Q.ring[(bi + 2) % 3];
+    while (prev.done.load(std::memory_order_acquire) == 0) futex_wait(prev.done, 0);            // one launch in flight at a time
+    // gathering wait: the callers the previous launch carried are waking up this very moment and will be back within ~0.2 ms; launching
+    // without them makes two cohorts that take turns (each launch half as full as it could be at the same cost)
+    long long ns_gather = 0;
+    const long long prev_done_ns = Q.last_done_ns.load(std::memory_order_relaxed);
+    if (Q.returning.load(std::memory_order_acquire) > 0) {
+        const long long t_in = steady_ns();
+        if (t_in - prev_done_ns > 1000000) {
+            Q.returning.store(0, std::memory_order_relaxed);                                     // stale: those callers went elsewhere long ago
         } else {
-            rc = me.kind == 0 ? run_combined(c, batch) : run_combined_pbs(c, batch);
-            if (rc) {
-                // A combined launch can fail for a reason that only the COMBINATION has -- the sum of the requests needs buffers a
-                // frozen context (captured hipGraph) may not grow, or page-locked staging that cannot be had -- while each request
-                // on its own would succeed.  The header promises every caller what a lone call returns: re-issue the batch's requests
-                // one by one through the serial path, each with its own result.  (Nothing of a failed launch has reached a caller's
-                // output: rows are handed out only behind a successful launch.)
-                for (auto *r : batch) {
-                    const int rr = serial(*r);
-                    if (r == &me) { rc = rr; if (rr) err = g_err; continue; }
-                    r->rc = rr;
-                    if (rr) r->err = g_err;
-                }
-                individually = true;
+            // the first kGatherSpinNs busy-polling (the GPU is idle and every caller of the context is waiting for this launch: a sleeping
+            // leader adds a second thread wake-up -- 50-100 us out of an idle core -- to every round), then asleep on the futex word
+            constexpr long long kGatherSpinNs = 120000;
+            auto gathered = [&]() { return Q.returning.load(std::memory_order_acquire) <= 0 || bt.full.load(std::memory_order_acquire); };
+            bool done = gathered();
+            while (!done && steady_ns() - t_in < kGatherSpinNs) {
+                for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+                done = gathered();
+            }
+            while (!done) {
+                const uint32_t g = Q.gather.load(std::memory_order_acquire);
+                const uint64_t seen = bt.claim.load(std::memory_order_acquire);
+                if (gathered()) break;
+                futex_wait(Q.gather, g, 150);
+                if (bt.claim.load(std::memory_order_acquire) == seen || steady_ns() - t_in > 600000) break;      // quiet for 150 us, or 600 us in all
+            }
+            Q.returning.store(0, std::memory_order_relaxed);
+            ns_gather = steady_ns() - t_in;
+        }
+    }
+    // close; open the next batch (its slot was the one before the previous: every follower of that launch has long taken its rows)
+    const uint64_t closed = bt.claim.fetch_or(Batch::kClosed, std::memory_order_acq_rel);
+    const int rows = (int)(closed & (Batch::kClosed - 1));
+    {
+        const int ni = (bi + 1) % 3;
+        Batch &nb = Q.ring[ni];
+        while (nb.readers.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+        nb.filled.store(0, std::memory_order_relaxed); nb.nreq.store(0, std::memory_order_relaxed);
+        nb.any_c.store(false, std::memory_order_relaxed); nb.full.store(false, std::memory_order_relaxed);
+        nb.done.store(0, std::memory_order_relaxed);
+        nb.claim.store(0, std::memory_order_release);
+        Q.open.store(ni, std::memory_order_release);
+        Q.open_gen.fetch_add(1, std::memory_order_release);
+        futex_wake_all(Q.open_gen);
+    }
+    int rc = TFHE_OK;
+    std::string err;
+    int nfollow = 0;
+    if (rows == me.B) {
+        rc = serial(me, me.ops, me.a, me.b, me.cc, me.out);          // alone: the caller's own pointers, no staging
+        if (rc) { try { err = g_err; } catch (...) {} }
+    } else {
+        comb_copy_in(c, Q, bt, me);
+        for (int spins = 0; bt.filled.load(std::memory_order_acquire) < rows - me.B; spins++)      // followers still copying (microseconds)
+            if (spins > 64) std::this_thread::yield();
+        nfollow = bt.nreq.load(std::memory_order_acquire);
+        const long long t_issue = steady_ns();
+        rc = run_combined(c, Q, bt, me.kind, rows);
+        c->comb_ns_launch += steady_ns() - t_issue;
+        if (t_issue - prev_done_ns < 5000000) { c->comb_ns_idle += t_issue - prev_done_ns; c->comb_ns_gather += ns_gather; }      // back-to-back rounds only
+        const CombPlanes p = comb_planes(c, Q, bt, me.kind);
+        const size_t n1b = ((size_t)c->P.n + 1) * 4;
+        if (rc == TFHE_OK) {
+            c->comb_launches++;
+            c->comb_requests += nfollow + 1;
+            memcpy(me.out, p.out, (size_t)me.B * n1b);
+        } else {
+            // A combined launch can fail for a reason that only the COMBINATION has -- the sum of the requests needs buffers a frozen
+            // context (captured hipGraph) may not grow -- while each request on its own would succeed.  The header promises every caller
+            // what a lone call returns: re-issue the requests one by one from the staging, each with its own result.
+            auto redo = [&](tfhe_ctx::GateReq &r, uint32_t *out) {
+                const size_t at = (size_t)r.pos;
+                if (r.kind == 0) return serial(r, p.ops + at, (const uint32_t *)(p.a + at * n1b), (const uint32_t *)(p.b + at * n1b),
+                                               r.cc ? (const uint32_t *)(p.c + at * n1b) : nullptr, out);
+                tfhe_ctx::GateReq t{1, nullptr, 1, nullptr, nullptr, nullptr, nullptr, r.B};
+                return serial(t, nullptr, (const uint32_t *)(p.a + at * n1b), (const uint32_t *)(p.tv + at * (size_t)2 * c->P.N * 4), nullptr, out);
+            };
+            rc = redo(me, me.out);
+            if (rc) { try { err = g_err; } catch (...) {} }
+            for (int i = 0; i < nfollow; i++) {
+                tfhe_ctx::GateReq &r = *bt.reqs[(size_t)i];
+                r.rc = redo(r, (uint32_t *)(p.out + (size_t)r.pos * n1b));
+                if (r.rc) { try { r.err = g_err; } catch (...) {} }
             }
         }
-        lk.lock();
-    } catch (...) {                                       // std::bad_alloc of the vector / string copies
-        if (!lk.owns_lock()) lk.lock();
-        rc = TFHE_E_NOMEM;
-        try { err = "out of host memory while combining concurrent requests"; } catch (...) {}
     }
-    if (!individually)
-        for (auto *r : batch) {
-            if (r == &me) continue;
-            r->rc = rc;
-            if (rc) { try { r->err = err; } catch (...) {} }
-        }
-    Q.last_done = std::chrono::steady_clock::now();
-    for (auto *r : batch)
-        if (r != &me) r->state.store(1, std::memory_order_release);   // the request object may die from here on: nothing touches it afterwards
-    if (batch.empty()) {                                  // the catch path before `me` was taken: take it out of the queue
-        for (auto it = Q.pending.begin(); it != Q.pending.end(); ++it) if (*it == &me) { Q.pending.erase(it); break; }
-    }
-    if (Q.pending.empty()) Q.leader = false;
-    else Q.pending.front()->state.store(2, std::memory_order_release);      // leadership passes to the oldest waiter
-    lk.unlock();
-    Q.gen.fetch_add(1, std::memory_order_release);
-    syscall(SYS_futex, reinterpret_cast<uint32_t *>(&Q.gen), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+    // settle: followers may read their request and their rows from here on
+    bt.readers.store(nfollow, std::memory_order_relaxed);
+    Q.last_done_ns.store(steady_ns(), std::memory_order_relaxed);
+    Q.returning.store(nfollow + 1, std::memory_order_release);
+    bt.done.store(1, std::memory_order_release);
+    futex_wake_all(bt.done);
     if (rc) g_err = err;
     return rc;
 }
@@ -1110,6 +1197,22 @@ int check_status(tfhe_ctx *c)
 extern "C" {
 
 const char *tfhe_last_error(void) { return g_err.c_str(); }
+
+// "release", or the name of the deliberate-defect control this object was compiled with (tests/fuzz_gpu.py's and the ThreadSanitizer
+// script's positive controls: they return WRONG ciphertexts / race on purpose).  Loaders refuse anything but "release" unless a test
+// opts in, so a stray -D in a packaging build cannot ship silently.
+const char *tfhe_build_flavor(void)
+{
+#if defined(TFHE_FUZZ_CONTROL)
+#warning "TFHE_FUZZ_CONTROL: this build returns one wrong bit on purpose (fuzzer positive control) -- never ship it"
+    return "control:fuzz";
+#elif defined(TFHE_TSAN_CONTROL)
+#warning "TFHE_TSAN_CONTROL: this build contains a deliberate data race (ThreadSanitizer positive control) -- never ship it"
+    return "control:tsan";
+#else
+    return "release";
+#endif
+}
 
 int tfhe_device_count(int *count)
 {
@@ -1157,6 +1260,11 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     c->oct_limit = c->num_cus;
     c->ks_mfma_min = kKsMfmaMinDefault;
     c->combine_max = launch_items(c);      // requests of up to one launch's worth of gates are combined (tfhe_gate_batch)
+    for (int kind = 0; kind < 2; kind++) {  // the combining queues: batch 0 open, the other two idle (closed, done)
+        c->comb[kind].cap_rows = combine_rows(c, kind);
+        c->comb[kind].ring[0].done.store(0);
+        c->comb[kind].ring[0].claim.store(0);
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &pair : c->ev)
         for (auto &e : pair) HIP_TRY(hipEventCreate(&e));
@@ -1190,14 +1298,15 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     if (c->need_sync_all) (void)hipDeviceSynchronize();
     c->dev_marks.clear();
     for (DevBuf *b : {&c->bsk, &c->bskq, &c->twq, &c->status, &c->s_plan, &c->ksk, &c->tw, &c->gate_tv, &c->s_in0, &c->s_in1, &c->s_in2, &c->s_out, &c->s_trlwe,
-                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3, &c->kskB, &c->s_onehot})
+                      &c->s_tv, &c->s_ops, &c->s_idx, &c->s_t0, &c->s_t1, &c->s_t2, &c->s_t3, &c->kskB, &c->s_onehot, &c->s_gsw_raw, &c->s_gsw})
         b->release();
     for (auto &pair : c->ev)
         for (auto &e : pair) if (e) (void)hipEventDestroy(e);
     for (auto &v : c->tev)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
-    if (c->comb_host) (void)hipHostFree(c->comb_host);
+    for (auto &Q : c->comb)
+        for (auto &b : Q.ring) if (b.host) (void)hipHostFree(b.host);
     for (void *h : c->hdr_host) if (h) (void)hipHostFree(h);
     for (auto &pr : c->pipe_ev)
         for (auto &e : pr) if (e) (void)hipEventDestroy(e);
@@ -1270,6 +1379,9 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     // the counters are 64-bit; the option interface is int: saturate instead of wrapping
     case TFHE_OPT_COMBINE_LAUNCHES: *value = (int)std::min<long long>(c->comb_launches.load(), INT_MAX); return TFHE_OK;
     case TFHE_OPT_COMBINE_REQUESTS: *value = (int)std::min<long long>(c->comb_requests.load(), INT_MAX); return TFHE_OK;
+    case TFHE_OPT_COMBINE_US_IDLE: *value = (int)std::min<long long>(c->comb_ns_idle.load() / 1000, INT_MAX); return TFHE_OK;
+    case TFHE_OPT_COMBINE_US_GATHER: *value = (int)std::min<long long>(c->comb_ns_gather.load() / 1000, INT_MAX); return TFHE_OK;
+    case TFHE_OPT_COMBINE_US_LAUNCH: *value = (int)std::min<long long>(c->comb_ns_launch.load() / 1000, INT_MAX); return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);
     }
 }
@@ -1541,7 +1653,7 @@ int tfhe_key_import_dev(tfhe_ctx *c, int which, const void *d_src, size_t bytes,
         if ((rc = make_mfma_ksk(c, st))) return rc;
         c->have_ksk = true;
     }
-    return TFHE_OK;
+    return mark_dev_stream(c, st);      // the install is only ENQUEUED: tfhe_ctx_sync, tfhe_ctx_destroy and tfhe_ctx_clone_to wait for it through this mark
 }
 
 // Host-memory forms of the blobs (persist a GPU-generated cloud key, hand it to another process / machine).
@@ -1612,16 +1724,25 @@ int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out)
 {
     if (!src || !out) return fail(TFHE_E_INVALID, "null argument");
     *out = nullptr;
+    int rc = check_ctx(src);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(src->mu);            // no key load on the source while it is being read
+    // Whatever the source still has in flight that WRITES its keys must be complete before they are read from another stream / device:
+    // tfhe_key_import_dev only enqueues its copy and the derived layouts on the caller's stream (it records the stream's mark), so a
+    // clone issued right behind an asynchronous import -- the RCCL-broadcast flow -- would otherwise replicate a half-written key
+    // (ADVICE r05).  The source's device is current here (check_ctx).
+    HIP_TRY(hipStreamSynchronize(src->stream));
+    for (auto &m : src->dev_marks) HIP_TRY(hipEventSynchronize(m.ev));
+    if (src->need_sync_all) HIP_TRY(hipDeviceSynchronize());
     tfhe_ctx *dst = nullptr;
-    int rc = tfhe_ctx_create(&src->P, device_id, &dst);           // validates device_id; leaves device_id current
+    rc = tfhe_ctx_create(&src->P, device_id, &dst);               // validates device_id; leaves device_id current
     if (rc) return rc;
     struct Guard {
         tfhe_ctx *c;
         ~Guard() { if (c) tfhe_ctx_destroy(c); }
     } guard{dst};
-    std::lock_guard<std::recursive_mutex> lk(src->mu);            // no key load on the source while it is being read
     // the per-context limits travel with the key: a clone dispatches like its source
-    dst->quad_limit = src->quad_limit; dst->oct_limit = src->oct_limit; dst->ks_mfma_min = src->ks_mfma_min;
+    dst->quad_limit = src->quad_limit.load(); dst->oct_limit = src->oct_limit.load(); dst->ks_mfma_min = src->ks_mfma_min;
     dst->ks_wide_ct = src->ks_wide_ct; dst->combine_max = src->combine_max.load();
     bool peers = false;
     void *bounce = nullptr;
@@ -1859,6 +1980,118 @@ int tfhe_external_product_batch(tfhe_ctx *c, int key_index, const uint32_t *in, 
                             c->s_t0.as<uint32_t>(), c->offset, B, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->s_t0.p, trl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+// ---- trgsw / trlwe seams with caller-supplied operands (SURVEY.md 8(b) seam 3) ------------------------------------------------
+namespace {
+// One TRGSWLv1FFT (trgsw.go:60-68) in the reference FourierPoly layout, [2L][2][N] float64, brought into the wave-native layout
+// the external-product kernels read (the key-ingest kernels with n = 1): c->s_gsw.  Enqueued on the context stream.
+int stage_trgsw(tfhe_ctx *c, const double *trgsw)
+{
+    const size_t elems = (size_t)2 * c->P.L * 2 * (c->P.N / 2), bytes = elems * sizeof(cd);
+    int rc;
+    if ((rc = c->s_gsw_raw.reserve(bytes)) || (rc = c->s_gsw.reserve(bytes))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_gsw_raw.p, trgsw, bytes, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)((elems + 255) / 256));
+    if (shape_is_1024(c->shape))
+        hipLaunchKernelGGL(k_bsk_from_fourier, grid, dim3(256), 0, c->stream, c->s_gsw_raw.as<double>(), c->s_gsw.as<cd>(), 1, c->P.L);
+    else if (shape_is_512(c->shape))
+        hipLaunchKernelGGL(k_bsk_from_fourier_512, grid, dim3(256), 0, c->stream, c->s_gsw_raw.as<double>(), c->s_gsw.as<cd>(), 1);
+    else
+        hipLaunchKernelGGL(k_bsk_from_fourier_2048, grid, dim3(256), 0, c->stream, c->s_gsw_raw.as<double>(), c->s_gsw.as<cd>(), 1);
+    HIP_TRY(hipGetLastError());
+    return TFHE_OK;
+}
+}
+
+int tfhe_ctx_decomposition_offset(tfhe_ctx *c, uint32_t *offset)
+{
+    if (!c || !offset) return fail(TFHE_E_INVALID, "null argument");
+    *offset = c->offset;
+    return TFHE_OK;
+}
+
+int tfhe_external_product_with(tfhe_ctx *c, const double *trgsw, uint32_t decomposition_offset, const uint32_t *in, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!trgsw) return fail(TFHE_E_INVALID, "null TRGSW operand");
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t trl = (size_t)B * 2 * c->P.N * 4;
+    if ((rc = grow(c, c->s_trlwe, trl, c->stream, "TRLWE accumulator")) || (rc = grow(c, c->s_t0, trl, c->stream, "temporary"))) return rc;
+    if ((rc = stage_trgsw(c, trgsw))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
+    launch_external_product(c->shape, c->s_gsw.as<cd>(), c->tw.as<cd>(), 0, c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(),
+                            decomposition_offset, B, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->s_t0.p, trl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_cmux_with(tfhe_ctx *c, const double *trgsw, uint32_t decomposition_offset, const uint32_t *ct0, const uint32_t *ct1,
+                   uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (!trgsw) return fail(TFHE_E_INVALID, "null TRGSW operand");
+    if (B < 0 || (B > 0 && (!ct0 || !ct1 || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t words = (size_t)B * 2 * c->P.N, trl = words * 4;
+    if ((rc = grow(c, c->s_trlwe, 2 * trl, c->stream, "TRLWE accumulator")) || (rc = grow(c, c->s_t0, trl, c->stream, "temporary")) ||
+        (rc = grow(c, c->s_t1, trl, c->stream, "temporary"))) return rc;
+    if ((rc = stage_trgsw(c, trgsw))) return rc;
+    uint32_t *d0 = c->s_trlwe.as<uint32_t>(), *d1 = d0 + words, *diff = c->s_t0.as<uint32_t>(), *prod = c->s_t1.as<uint32_t>();
+    HIP_TRY(hipMemcpyAsync(d0, ct0, trl, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d1, ct1, trl, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((unsigned)((words + 255) / 256));
+    hipLaunchKernelGGL(k_torus_addsub<true>, grid, dim3(256), 0, c->stream, (const uint32_t *)d1, (const uint32_t *)d0, diff, words);      // ct1 - ct0
+    launch_external_product(c->shape, c->s_gsw.as<cd>(), c->tw.as<cd>(), 0, diff, prod, decomposition_offset, B, c->stream);
+    hipLaunchKernelGGL(k_torus_addsub<false>, grid, dim3(256), 0, c->stream, (const uint32_t *)d0, (const uint32_t *)prod, prod, words);   // ct0 + product
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, prod, trl, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_sample_extract_batch(tfhe_ctx *c, const uint32_t *in, int k, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (k < 0 || k >= c->P.N) return fail(TFHE_E_INVALID, "sample-extract index %d outside [0, %d)", k, c->P.N);
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t trl = (size_t)B * 2 * c->P.N * 4, outb = (size_t)B * (c->P.N + 1) * 4;
+    if ((rc = grow(c, c->s_trlwe, trl, c->stream, "TRLWE accumulator")) || (rc = grow(c, c->s_t0, outb, c->stream, "temporary"))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_trlwe.p, in, trl, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_sample_extract, dim3(B), dim3(256), 0, c->stream, (const uint32_t *)c->s_trlwe.as<uint32_t>(), c->s_t0.as<uint32_t>(), c->P.N, k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->s_t0.p, outb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TFHE_OK;
+}
+
+int tfhe_keyswitch_batch(tfhe_ctx *c, const uint32_t *in, uint32_t *out, int B)
+{
+    int rc = check_ctx(c);
+    if (rc) return rc;
+    if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
+    if (B == 0) return TFHE_OK;
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    const size_t inb = (size_t)B * (c->P.N + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4, outb = (size_t)B * (c->P.n + 1) * 4;
+    if ((rc = c->s_out.reserve(outb)) || (rc = grow(c, c->s_trlwe, trl, c->stream, "TRLWE accumulator")) ||
+        (rc = grow(c, c->s_t2, inb, c->stream, "temporary"))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->s_t2.p, in, inb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_unextract, dim3(B), dim3(256), 0, c->stream, (const uint32_t *)c->s_t2.as<uint32_t>(), c->s_trlwe.as<uint32_t>(), c->P.N);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_keyswitch(c, c->s_trlwe.as<uint32_t>(), c->s_out.as<uint32_t>(), B, nullptr, c->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->s_out.p, outb, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TFHE_OK;
 }

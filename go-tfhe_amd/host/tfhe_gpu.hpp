@@ -74,6 +74,14 @@ struct TLWELv0 {
     TLWELv0 AddMul(const TLWELv0 &o, params::Torus m) const { TLWELv0 r = *this; for (size_t i = 0; i < P.size(); i++) r.P[i] = P[i] + o.P[i] * m; return r; }
     TLWELv0 SubMul(const TLWELv0 &o, params::Torus m) const { TLWELv0 r = *this; for (size_t i = 0; i < P.size(); i++) r.P[i] = P[i] - o.P[i] * m; return r; }
 };
+// tlwe.go:36-73: a level-1 sample, N mask words and the body last (what SampleExtractIndex produces, IdentityKeySwitching consumes)
+struct TLWELv1 {
+    std::vector<params::Torus> P;
+    TLWELv1() = default;
+    explicit TLWELv1(int N) : P((size_t)N + 1, 0u) {}
+    params::Torus B() const { return P.back(); }
+    void SetB(params::Torus v) { P.back() = v; }
+};
 } // namespace tlwe
 
 namespace trlwe {
@@ -308,6 +316,94 @@ class Generator {
 };
 } // namespace lut
 
+namespace trgsw {
+// trgsw.go:60-68: 2L TRLWE rows in the Fourier domain, kept flat: [2L][2][N] float64, row r = TRLWEFFT[r].A.Coeffs then .B.Coeffs in
+// the reference's own FourierPoly layout (what one element of the flattened bootstrapping key is).
+struct TRGSWLv1FFT {
+    std::vector<double> Flat;
+    TRGSWLv1FFT() = default;
+    TRGSWLv1FFT(const double *src, const params::Params &p) : Flat(src, src + (size_t)2 * p.L * 2 * p.N) {}
+};
+namespace detail_t {
+inline std::vector<uint32_t> flat(const trlwe::TRLWELv1 &t)
+{
+    std::vector<uint32_t> f(t.A);
+    f.insert(f.end(), t.B.begin(), t.B.end());
+    return f;
+}
+inline trlwe::TRLWELv1 unflat(const uint32_t *f, size_t N)
+{
+    trlwe::TRLWELv1 t;
+    t.A.assign(f, f + N);
+    t.B.assign(f + N, f + 2 * N);
+    return t;
+}
+inline void want_offset(const cloudkey::CloudKey &ck, params::Torus off)
+{
+    uint32_t mine = 0;
+    check(tfhe_ctx_decomposition_offset(ck.ctx(), &mine));
+    if (mine != off) throw Panic(TFHE_E_INVALID, "decompositionOffset differs from the cloud key's (cloudkey.go:60-71): the blind rotation uses the context's");
+}
+} // namespace detail_t
+// trgsw.go:108-137
+inline trlwe::TRLWELv1 ExternalProductWithFFT(const TRGSWLv1FFT &g, const trlwe::TRLWELv1 &in, params::Torus decompositionOffset, const cloudkey::CloudKey &ck)
+{
+    const size_t N = (size_t)ck.P.N;
+    std::vector<uint32_t> f = detail_t::flat(in), out(2 * N);
+    check(tfhe_external_product_with(ck.ctx(), g.Flat.data(), decompositionOffset, f.data(), out.data(), 1));
+    return detail_t::unflat(out.data(), N);
+}
+// trgsw.go:173-194: in1 where cond encrypts 0, in2 where it encrypts 1
+inline trlwe::TRLWELv1 CMUX(const trlwe::TRLWELv1 &in1, const trlwe::TRLWELv1 &in2, const TRGSWLv1FFT &cond, params::Torus decompositionOffset, const cloudkey::CloudKey &ck)
+{
+    const size_t N = (size_t)ck.P.N;
+    std::vector<uint32_t> f1 = detail_t::flat(in1), f2 = detail_t::flat(in2), out(2 * N);
+    check(tfhe_cmux_with(ck.ctx(), cond.Flat.data(), decompositionOffset, f1.data(), f2.data(), out.data(), 1));
+    return detail_t::unflat(out.data(), N);
+}
+// trgsw.go:234-252 (and :197-224 with one input): the bootstrapping key is the one resident in `ck`
+inline std::vector<trlwe::TRLWELv1> BatchBlindRotate(const std::vector<tlwe::TLWELv0> &srcs, const trlwe::TRLWELv1 &testvec, params::Torus decompositionOffset,
+                                                     const cloudkey::CloudKey &ck)
+{
+    detail_t::want_offset(ck, decompositionOffset);
+    const size_t N = (size_t)ck.P.N, n1 = (size_t)ck.P.n + 1;
+    std::vector<uint32_t> in(srcs.size() * n1), tv = detail_t::flat(testvec), out(srcs.size() * 2 * N);
+    for (size_t i = 0; i < srcs.size(); i++) {
+        if (srcs[i].P.size() != n1) throw Panic(TFHE_E_INVALID, "ciphertext length");
+        std::copy(srcs[i].P.begin(), srcs[i].P.end(), in.begin() + i * n1);
+    }
+    check(tfhe_blind_rotate_batch(ck.ctx(), in.data(), tv.data(), 0, out.data(), (int)srcs.size(), -1));
+    std::vector<trlwe::TRLWELv1> res;
+    for (size_t i = 0; i < srcs.size(); i++) res.push_back(detail_t::unflat(out.data() + i * 2 * N, N));
+    return res;
+}
+inline trlwe::TRLWELv1 BlindRotate(const tlwe::TLWELv0 &src, const trlwe::TRLWELv1 &testvec, params::Torus decompositionOffset, const cloudkey::CloudKey &ck)
+{
+    return BatchBlindRotate({src}, testvec, decompositionOffset, ck)[0];
+}
+// trgsw.go:285-312, keyswitch.go:10-37: the key-switching key is the one resident in `ck`
+inline tlwe::TLWELv0 IdentityKeySwitching(const tlwe::TLWELv1 &src, const cloudkey::CloudKey &ck)
+{
+    if (src.P.size() != (size_t)ck.P.N + 1) throw Panic(TFHE_E_INVALID, "TLWELv1 length");
+    tlwe::TLWELv0 out(ck.P.n);
+    check(tfhe_keyswitch_batch(ck.ctx(), src.P.data(), out.P.data(), 1));
+    return out;
+}
+inline void IdentityKeySwitchingAssign(const tlwe::TLWELv1 &src, const cloudkey::CloudKey &ck, tlwe::TLWELv0 &output) { output = IdentityKeySwitching(src, ck); }
+} // namespace trgsw
+
+namespace trlwe {
+// trlwe.go:114-128, trlwe_ops.go:10-21 (any index k)
+inline tlwe::TLWELv1 SampleExtractIndex(const TRLWELv1 &t, int k, const cloudkey::CloudKey &ck)
+{
+    tlwe::TLWELv1 out(ck.P.N);
+    const std::vector<uint32_t> f = trgsw::detail_t::flat(t);
+    check(tfhe_sample_extract_batch(ck.ctx(), f.data(), k, out.P.data(), 1));
+    return out;
+}
+inline void SampleExtractIndexAssign(const TRLWELv1 &t, int k, const cloudkey::CloudKey &ck, tlwe::TLWELv1 &output) { output = SampleExtractIndex(t, k, ck); }
+} // namespace trlwe
+
 namespace evaluator {
 // evaluator.go:14-35.  The bsk / ksk / decompositionOffset arguments of the Go methods are the
 // ones resident in the CloudKey; outputs are caller-owned (the *Assign style).
@@ -325,6 +421,15 @@ class Evaluator {
         check(tfhe_external_product_batch(ck_.ctx(), keyIndex, in.data(), out.data(), 1));
         ctOut.A.assign(out.begin(), out.begin() + N);
         ctOut.B.assign(out.begin() + N, out.end());
+    }
+    // evaluator.go:50-81 with any operand, and evaluator.go:85-106: ctOut = ct0 + ctCond (x) (ct1 - ct0)
+    void ExternalProductAssign(const trgsw::TRGSWLv1FFT &ctFourierGGSW, const trlwe::TRLWELv1 &ctIn, params::Torus decompositionOffset, trlwe::TRLWELv1 &ctOut) const
+    {
+        ctOut = trgsw::ExternalProductWithFFT(ctFourierGGSW, ctIn, decompositionOffset, ck_);
+    }
+    void CMuxAssign(const trgsw::TRGSWLv1FFT &ctCond, const trlwe::TRLWELv1 &ct0, const trlwe::TRLWELv1 &ct1, params::Torus decompositionOffset, trlwe::TRLWELv1 &ctOut) const
+    {
+        ctOut = trgsw::CMUX(ct0, ct1, ctCond, decompositionOffset, ck_);
     }
     // evaluator.go:110-135 ; testvec == nullptr selects the gate test vector (cloudkey.go:74-85)
     void BlindRotateAssign(const tlwe::TLWELv0 &ctIn, const trlwe::TRLWELv1 *testvec, trlwe::TRLWELv1 &ctOut) const

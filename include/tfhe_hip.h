@@ -71,6 +71,9 @@ enum {
 typedef struct tfhe_ctx tfhe_ctx;
 
 const char *tfhe_last_error(void);
+/* "release" for every build that may be used; "control:fuzz" / "control:tsan" for the two test-only variants that misbehave on purpose
+ * (the differential fuzzer's and the ThreadSanitizer script's positive controls).  A loader should refuse anything but "release". */
+const char *tfhe_build_flavor(void);
 /* Number of visible GPUs (hipGetDeviceCount). */
 int tfhe_device_count(int *count);
 
@@ -120,6 +123,10 @@ enum {
                                   (see tfhe_gate_batch); default (and -1) = one launch's worth, 0 = never                  */
     TFHE_OPT_COMBINE_LAUNCHES = 6,  /* read-only: combined launches issued so far ...                                       */
     TFHE_OPT_COMBINE_REQUESTS = 7,  /* ... and the tfhe_gate_batch calls they carried                                       */
+    TFHE_OPT_COMBINE_US_IDLE = 11,  /* read-only, microseconds summed over the combined launches of back-to-back rounds: from the previous
+                                       launch's completion to this one's issue (the GPU-idle gap combining leaves between rounds) ...    */
+    TFHE_OPT_COMBINE_US_GATHER = 12,/* ... the part of it the launch's leader spent waiting for the previous launch's callers to return ... */
+    TFHE_OPT_COMBINE_US_LAUNCH = 13,/* ... and transfers + kernels + synchronisation of the combined launches themselves                   */
     TFHE_OPT_KS_WIDE_CT = 8,   /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
                                   only: one wave per SIMD, slower)                                                         */
     TFHE_OPT_CLONE_FORCE_HOST = 10, /* tests: 1 = clones OF this context take the host-staged path (the fallback of devices that are
@@ -188,7 +195,9 @@ int tfhe_key_import(tfhe_ctx *ctx, int which, const void *src, size_t bytes);
  * contexts on one GPU are two independent submitters); the target then derives what a key load derives.  No host copy of the
  * keys is made.  Fallback when the devices are NOT peers: the copy is staged through 32 MB of page-locked host memory
  * (what tfhe_key_export + tfhe_key_import do, without the full-size host blob).  TFHE_OPT_CLONE_PATH on the new context
- * says which of the three happened.  Synchronous; the source may be used by other threads meanwhile (its keys are immutable
+ * says which of the three happened.  Synchronous, and ordered behind everything the source has pending: its private stream and
+ * every "_dev" call so far, tfhe_key_import_dev included (a clone issued right behind an asynchronous import replicates the
+ * complete key).  The source may be used by other threads meanwhile (its keys are immutable
  * after load; key loads on it wait).  The replica is an ordinary context: tfhe_ctx_destroy it.  One goroutine / thread per
  * replica, contiguous shards, results in index order is all the multi-GPU form of gates.Batch* needs (SURVEY.md 8e;
  * shim/go/gpu: CloudKeySet, go-tfhe_amd/host/tfhe_gpu.hpp: cloudkey::CloudKeySet). */
@@ -238,6 +247,33 @@ int tfhe_blind_rotate_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in, const uint3
  * element bsk[key_index]: in/out [B][2][N]. */
 int tfhe_external_product_batch(tfhe_ctx *ctx, int key_index, const uint32_t *in_trlwe,
                                 uint32_t *out_trlwe, int B);
+
+/* The decomposition offset the context derived from its parameters (cloudkey.go:60-71, CloudKey.DecompositionOffset): what the
+ * reference's callers pass as `decompositionOffset` to trgsw.BlindRotate / BatchBlindRotate (trgsw.go:197,234); a shim compares the
+ * caller's value with this one before it routes such a call to tfhe_blind_rotate_batch (which always uses the context's). */
+int tfhe_ctx_decomposition_offset(tfhe_ctx *ctx, uint32_t *offset);
+
+/* trgsw.ExternalProductWithFFT (trgsw.go:108-137) / Evaluator.ExternalProductAssign (evaluator.go:50-81) with ANY TRGSW operand --
+ * not only an element of the loaded bootstrapping key (tfhe_external_product_batch): the same operand for the whole batch.
+ *   trgsw_fourier [2L][2][N] float64: TRLWEFFT[r].A.Coeffs then .B.Coeffs, r < 2L, each in the reference's own FourierPoly layout
+ *                 and slot order (trgsw.go:60-68, poly.go:54-62) -- one element of what tfhe_load_bsk_fourier takes n of
+ *   decomposition_offset: the caller's `decompositionOffset` argument (any value: it is a kernel operand, not context state)
+ *   in / out      [B][2][N]
+ * Needs no loaded key.  Exactness follows the parameter shape as everywhere. */
+int tfhe_external_product_with(tfhe_ctx *ctx, const double *trgsw_fourier, uint32_t decomposition_offset,
+                               const uint32_t *in_trlwe, uint32_t *out_trlwe, int B);
+/* trgsw.CMUX(in1, in2, cond) (trgsw.go:173-194) / Evaluator.CMuxAssign(ctCond, ct0, ct1) (evaluator.go:85-106):
+ * out[b] = ct0[b] + cond (x) (ct1[b] - ct0[b]), i.e. ct0 where cond encrypts 0 and ct1 where it encrypts 1.  Operand as above. */
+int tfhe_cmux_with(tfhe_ctx *ctx, const double *trgsw_fourier, uint32_t decomposition_offset, const uint32_t *ct0_trlwe,
+                   const uint32_t *ct1_trlwe, uint32_t *out_trlwe, int B);
+
+/* trlwe.SampleExtractIndex / SampleExtractIndexAssign for ANY index k in [0, N) (trlwe.go:114-128, trlwe_ops.go:10-21):
+ * in [B][2][N] -> out [B][N+1] (a tlwe.TLWELv1: N mask words, body last).  The bootstrap itself only ever uses k = 0, fused into the
+ * key switch (tfhe_extract_keyswitch_batch); this is the seam on its own. */
+int tfhe_sample_extract_batch(tfhe_ctx *ctx, const uint32_t *in_trlwe, int k, uint32_t *out_lwe1, int B);
+/* trgsw.IdentityKeySwitching / IdentityKeySwitchingAssign (trgsw.go:285-312, keyswitch.go:10-37) on already-extracted samples:
+ * in [B][N+1] (tlwe.TLWELv1) -> out [B][n+1].  Runs the same key-switch kernels as the fused form (bit-exact with it). */
+int tfhe_keyswitch_batch(tfhe_ctx *ctx, const uint32_t *in_lwe1, uint32_t *out, int B);
 
 /* trlwe.SampleExtractIndexAssign(.,0,.) + trgsw.IdentityKeySwitchingAssign
  * (trlwe_ops.go:10-21, keyswitch.go:10-37): in [B][2][N] -> out [B][n+1]. */

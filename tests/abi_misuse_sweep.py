@@ -28,13 +28,13 @@ ksk = o.keygen_ksk(p, rng, s0, s1)
 ck = pkg.CloudKey(pkg.Params(n=p.n, N=p.N, Nbit=p.Nbit, L=p.L, Bgbit=p.Bgbit, basebit=p.basebit, t=p.t), bsk_fourier=bsk, ksk=ksk)
 h = ck.ctx._h
 
-NO_CTX = {"tfhe_device_count", "tfhe_ctx_create", "tfhe_host_alloc", "tfhe_host_free", "tfhe_last_error"}
+NO_CTX = {"tfhe_device_count", "tfhe_ctx_create", "tfhe_host_alloc", "tfhe_host_free", "tfhe_last_error", "tfhe_build_flavor"}
 MAY_ACCEPT_NULL = {"tfhe_ctx_destroy", "tfhe_host_free"}          # destroying / freeing nothing is not an error
 results = {}
 
 
 def zero(t):
-    if t in (C.c_int, C.c_uint64, C.c_size_t):
+    if t in (C.c_int, C.c_uint32, C.c_uint64, C.c_size_t):
         return t(0)
     if t is C.c_double:
         return t(0.0)
@@ -43,7 +43,7 @@ def zero(t):
 
 for name in pkg.declared_symbols():
     fn = getattr(lib, name)
-    if name in ("tfhe_last_error", "tfhe_ctx_destroy"):
+    if name in ("tfhe_last_error", "tfhe_build_flavor", "tfhe_ctx_destroy"):          # no status code to sweep
         continue
     at = fn.argtypes
     row = {}

@@ -130,6 +130,47 @@ int main()
     orc_gate_testvec(&op, tv.data());
     orc_blind_rotate(&op, fft, bsk.data(), prep.P.data(), tv.data(), -1, want.data());
     EXPECT(std::equal(acc.A.begin(), acc.A.end(), want.begin()) && std::equal(acc.B.begin(), acc.B.end(), want.begin() + op.N), "BlindRotateAssign");
+    // trgsw / trlwe seams with caller-supplied operands (SURVEY 8b seam 3): one blind rotation rebuilt step by step OUTSIDE the engine's
+    // persistent kernel -- X^a rotation by the oracle, CMuxAssign with bsk[i] handed over as a free-standing TRGSWLv1FFT -- must end
+    // in the same words as BlindRotateAssign; then SampleExtractIndex + IdentityKeySwitching == the fused bootstrap output
+    {
+        const uint32_t off = orc_decomposition_offset(&op);
+        const size_t gsw = (size_t)2 * op.L * 2 * op.N;
+        auto accs = trgsw::BatchBlindRotate({prep}, [&] { trlwe::TRLWELv1 t(op.N); std::copy(tv.begin(), tv.begin() + op.N, t.A.begin()); std::copy(tv.begin() + op.N, tv.end(), t.B.begin()); return t; }(), off, ck);
+        EXPECT(accs.size() == 1 && accs[0].A == acc.A && accs[0].B == acc.B, "trgsw::BatchBlindRotate differs from BlindRotateAssign");
+        // first 3 CMUX steps by hand
+        std::vector<uint32_t> cur(2 * op.N), rot(2 * op.N), wantp(2 * op.N);
+        orc_blind_rotate(&op, fft, bsk.data(), prep.P.data(), tv.data(), 0, cur.data());
+        for (int i = 0; i < 3; i++) {
+            const int at = (int)((uint32_t)(prep.P[i] + (1u << (31 - op.Nbit - 1))) >> (32 - op.Nbit - 1));
+            orc_poly_mul_xk(op.N, cur.data(), at, rot.data());
+            orc_poly_mul_xk(op.N, cur.data() + op.N, at, rot.data() + op.N);
+            trgsw::TRGSWLv1FFT g(bsk.data() + (size_t)i * gsw, p);
+            trlwe::TRLWELv1 c0 = trgsw::detail_t::unflat(cur.data(), op.N), c1 = trgsw::detail_t::unflat(rot.data(), op.N), out(op.N);
+            ev.CMuxAssign(g, c0, c1, off, out);
+            std::copy(out.A.begin(), out.A.end(), cur.begin());
+            std::copy(out.B.begin(), out.B.end(), cur.begin() + op.N);
+        }
+        orc_blind_rotate(&op, fft, bsk.data(), prep.P.data(), tv.data(), 3, wantp.data());
+        EXPECT(cur == wantp, "three CMuxAssign steps with free-standing TRGSW operands differ from the oracle's blind-rotate prefix");
+        trlwe::TRLWELv1 prod(op.N);
+        trgsw::TRGSWLv1FFT g5(bsk.data() + 5 * gsw, p);
+        ev.ExternalProductAssign(g5, acc, off, prod);
+        std::vector<uint32_t> accf = trgsw::detail_t::flat(acc), wante(2 * op.N);
+        orc_external_product(&op, fft, bsk.data() + 5 * gsw, accf.data(), wante.data());
+        EXPECT(trgsw::detail_t::flat(prod) == wante, "ExternalProductAssign with a free-standing operand differs from the oracle");
+        for (int k : {0, 1, 700}) {
+            auto ext = trlwe::SampleExtractIndex(acc, k, ck);
+            std::vector<uint32_t> wx(op.N + 1);
+            orc_sample_extract(op.N, accf.data(), k, wx.data());
+            EXPECT(ext.P == wx, "SampleExtractIndex(%d) differs from the oracle", k);
+        }
+        auto lv0 = trgsw::IdentityKeySwitching(trlwe::SampleExtractIndex(acc, 0, ck), ck);
+        EXPECT(lv0.P == ev.Bootstrap(prep).P, "SampleExtractIndex + IdentityKeySwitching differs from the fused bootstrap");
+        bool bad = false;
+        try { (void)trgsw::BlindRotate(prep, trlwe::TRLWELv1(op.N), off + 1, ck); } catch (const Panic &e) { bad = e.code == TFHE_E_INVALID; }
+        EXPECT(bad, "a decomposition offset other than the cloud key's must panic in BlindRotate");
+    }
     // lut package + BootstrapFunc (lut_test.go:10-215, programmable_bootstrap_test.go:13-188)
     {
         lut::Encoder e4(4);

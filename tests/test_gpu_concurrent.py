@@ -293,11 +293,14 @@ def test_concurrent_programmable_bootstraps_are_combined_and_bit_identical(oracl
         ck.close()
 
 
-def test_combined_gates_at_a_tolerance_regime_shape_equal_lone_calls(oracle, pkg):
+@pytest.mark.parametrize("op", ["XOR", "MUX"])
+def test_combined_gates_at_a_tolerance_regime_shape_equal_lone_calls(oracle, pkg, op):
     # at the shapes whose transforms are not exact (here Uint1: N = 1024, L = 2, Bgbit = 10) kernels of different
     # launch shapes round differently, so a combined GATE launch -- like a combined table bootstrap -- must stay within the
     # kernel shape a lone small call runs (at most one bootstrap per CU, within the four-/eight-wave limits): every caller's
     # words equal the same call issued alone with combining switched off, even when far more gates than CUs are in flight.
+    # "MUX" (ADVICE r05): a MUX row puts TWO bootstraps into pass 1 of the launch (its own AND and the ANDNY of the list), so the
+    # combiner must budget bootstraps, not rows -- 96 callers x 5 MUX rows = 960 bootstraps, against 256 per lone-shape launch.
     from conftest import KeySet, gpu_params
     k = KeySet(oracle, "uint1", 0x7F4E0071, n_override=24, torus=False)
     ck = pkg.CloudKey(gpu_params(pkg, k.p), bsk_fourier=k.bsk, ksk=k.ksk)
@@ -306,10 +309,10 @@ def test_combined_gates_at_a_tolerance_regime_shape_equal_lone_calls(oracle, pkg
         n1 = k.p.n + 1
         rs = np.random.RandomState(17)
         T = 96                                          # x 5 gates = 480 > the 256 CUs: more than one lone-shape launch
-        reqs = [(rs.randint(0, 2**32, size=(5, n1), dtype=np.uint64).astype(np.uint32),
-                 rs.randint(0, 2**32, size=(5, n1), dtype=np.uint64).astype(np.uint32)) for _ in range(T)]
+        rnd = lambda: rs.randint(0, 2**32, size=(5, n1), dtype=np.uint64).astype(np.uint32)
+        reqs = [(rnd(), rnd(), rnd() if op == "MUX" else None) for _ in range(T)]
         ctx.set_option("combine_max", 0)
-        want = [ctx.gate_batch("XOR", a, b) for a, b in reqs]
+        want = [ctx.gate_batch(op, a, b, c) for a, b, c in reqs]
         ctx.set_option("combine_max", -1)
         before = ctx.get_option("combine_requests")
         got = [None] * T
@@ -317,7 +320,7 @@ def test_combined_gates_at_a_tolerance_regime_shape_equal_lone_calls(oracle, pkg
 
         def run(i):
             gate.wait()
-            got[i] = ctx.gate_batch("XOR", *reqs[i])
+            got[i] = ctx.gate_batch(op, *reqs[i])
 
         ts = [threading.Thread(target=run, args=(i,)) for i in range(T)]
         for t in ts:

@@ -108,12 +108,19 @@ int main(int argc, char **argv)
     const double ms = run(T);
     CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_LAUNCHES, &l1));
     CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_REQUESTS, &r1));
+    int us_idle = 0, us_gather = 0, us_launch = 0;
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_US_IDLE, &us_idle));
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_US_GATHER, &us_gather));
+    CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_US_LAUNCH, &us_launch));
+    const int nl = l1 - l0 > 0 ? l1 - l0 : 1;
+    const bool quick = argc > 2 && std::string(argv[2]) == "quick";      // skip the serialised comparison (0.7 s)
     CK(tfhe_ctx_set_option(ctx, TFHE_OPT_COMBINE_MAX, 0));
     const int Ts = T < 8 ? T : 8;
-    const double serial = run(Ts);
+    const double serial = quick ? 0.0 : run(Ts);
     std::printf("{\"threads\": %d, \"gate_calls\": %d, \"ms\": %.1f, \"combined_launches\": %d, \"calls_carried\": %d, "
+                "\"per_combined_launch_us\": {\"idle_before\": %.0f, \"of_which_gathering\": %.0f, \"launch\": %.0f}, "
                 "\"one_thread_40_gates_ms\": %.1f, \"serialised_%d_threads_ms\": %.1f, \"serialised_all_threads_projected_ms\": %.0f}\n",
-                T, 40 * T, ms, l1 - l0, r1 - r0, one, Ts, serial, serial / Ts * T);
+                T, 40 * T, ms, l1 - l0, r1 - r0, (double)us_idle / nl, (double)us_gather / nl, (double)us_launch / nl, one, Ts, serial, serial / Ts * T);
     CK(tfhe_ctx_destroy(ctx));
     std::fflush(stdout);
     return 0;
