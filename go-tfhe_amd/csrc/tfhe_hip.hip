@@ -824,6 +824,7 @@ int gate_batch_serial(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uin
                       uint32_t *out, int B)
 {
     int rc;
+    HIP_TRY(hipSetDevice(c->device));        // here, not in tfhe_gate_batch: a caller that only FOLLOWS a combined launch never touches the HIP runtime
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (B > pipe_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
@@ -846,6 +847,7 @@ int gate_batch_serial(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uin
 int bootstrap_batch_serial(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out, int B)
 {
     int rc;
+    HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
     const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
@@ -918,6 +920,7 @@ int comb_ensure_staging(tfhe_ctx *c, int kind)
     if (Q.ready.load(std::memory_order_acquire)) return TFHE_OK;
     std::lock_guard<std::mutex> lk(Q.alloc_mu);
     if (Q.ready.load(std::memory_order_relaxed)) return TFHE_OK;
+    HIP_TRY(hipSetDevice(c->device));
     const size_t rows = (size_t)Q.cap_rows, n1 = (size_t)c->P.n + 1;
     const size_t bytes = kind == 0 ? 4 * rows * n1 * 4 + rows : 2 * rows * n1 * 4 + rows * 2 * c->P.N * 4;
     try {
@@ -982,11 +985,14 @@ void comb_copy_in(const tfhe_ctx *c, const tfhe_ctx::CombQueue &Q, tfhe_ctx::Com
 int run_combined(tfhe_ctx *c, tfhe_ctx::CombQueue &Q, tfhe_ctx::CombBatch &bt, int kind, int rows)
 {
     int rc;
+    HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t n1 = (size_t)c->P.n + 1, plane = (size_t)rows * n1 * 4;
     const CombPlanes p = comb_planes(c, Q, bt, kind);
     if (kind == 0) {
         const bool any_c = bt.any_c.load(std::memory_order_relaxed);
+        // (Measured and dropped, profiles/r06_c_combine.txt: letting the kernels of a small launch read the operand rows straight from the
+        // page-locked staging instead of making these transfers -- the launch got 0.14 ms LONGER, 2.51 vs 2.37 ms at 256 rows.)
         if ((rc = c->s_in0.reserve(plane)) || (rc = c->s_in1.reserve(plane)) || (rc = c->s_out.reserve(plane))) return rc;
         if (any_c && (rc = c->s_in2.reserve(plane))) return rc;
         if ((rc = c->s_ops.reserve((size_t)rows))) return rc;
@@ -1176,7 +1182,8 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
     Q.last_done_ns.store(steady_ns(), std::memory_order_relaxed);
     Q.returning.store(nfollow + 1, std::memory_order_release);
     bt.done.store(1, std::memory_order_release);
-    futex_wake_all(bt.done);
+    futex_wake_all(bt.done);      // ONE system call for all sleepers (0.55 us each on the GPU box).  Measured and dropped (profiles/r06_c_combine.txt):
+                                  // dealing the sleepers over four words with one relay waker per word -- every relay hop costs a thread wake-up, 134 vs 122 ms
     if (rc) g_err = err;
     return rc;
 }
@@ -1900,8 +1907,7 @@ int tfhe_extract_keyswitch_batch(tfhe_ctx *c, const uint32_t *in, uint32_t *out,
 
 int tfhe_bootstrap_batch(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out, int B)
 {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+    if (!c) return fail(TFHE_E_INVALID, "null context");          // the device is made current where HIP is called (serial path / leader)
     if (B < 0 || (B > 0 && (!in || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (B == 0) return TFHE_OK;
     if (!c->have_bsk) return fail(TFHE_E_NOKEY, "bootstrapping key not loaded");
@@ -1936,8 +1942,7 @@ int tfhe_bootstrap_extended_batch(tfhe_ctx *c, const uint32_t *in, const uint32_
 int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b,
                     const uint32_t *cc, uint32_t *out, int B)
 {
-    int rc = check_ctx(c);
-    if (rc) return rc;
+    if (!c) return fail(TFHE_E_INVALID, "null context");          // the device is made current where HIP is called (serial path / leader)
     if (B < 0 || (B > 0 && (!a || !b || !out))) return fail(TFHE_E_INVALID, "bad batch arguments");
     if (!c->have_bsk || !c->have_ksk) return fail(TFHE_E_NOKEY, "cloud key not loaded");
     if (B == 0) return TFHE_OK;
@@ -1954,7 +1959,7 @@ int tfhe_gate_batch(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint3
     // tests/fuzz_gpu.py's positive control (tools/build_variant_main.sh fuzzcontrol -DTFHE_FUZZ_CONTROL): ONE wrong bit in the last row of
     // a batch of exactly one more than the CU count -- the kind of dispatch-boundary defect the fuzzer's batch sizes are weighted to find
     if (B == c->num_cus + 1) {
-        rc = gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
+        const int rc = gate_batch_serial(c, ops, op_uniform, a, b, cc, out, B);
         out[(size_t)(B - 1) * ((size_t)c->P.n + 1)] ^= 1u;
         return rc;
     }

@@ -1,4 +1,4 @@
-// Package evaluator is the bootstrap surface of go-tfhe's evaluator package (evaluator/evaluator.go:110-157,
+// Package evaluator is the bootstrap surface of go-tfhe's evaluator package (evaluator/evaluator.go:50-157,
 // evaluator/programmable_bootstrap.go:16-115, evaluator/gates_helper.go:10-63) on the MI355X engine, with the reference's
 // method names and parameter lists: the keys arrive with every call, as in the reference, and are uploaded and replicated
 // to the GPUs once, on first use (gpu.Attached finds them again by identity).
@@ -46,6 +46,22 @@ func checkOffset(decompositionOffset params.Torus) {
 	if decompositionOffset != expectedOffset() {
 		panic("tfhe_hip: decompositionOffset is not the offset of the current parameters (cloudkey/cloudkey.go:60-71)")
 	}
+}
+
+// ExternalProductAssign: ctFourierGGSW (x) ctIn, into ctOut -- for ANY TRGSW operand, which travels with the call; the
+// decomposition offset is a kernel operand (any value).  Reference: evaluator/evaluator.go:50.
+func (e *Evaluator) ExternalProductAssign(ctFourierGGSW *trgsw.TRGSWLv1FFT, ctIn *trlwe.TRLWELv1, decompositionOffset params.Torus, ctOut *trlwe.TRLWELv1) {
+	res := gpu.Scratch().ExternalProductWith(ctFourierGGSW, []*trlwe.TRLWELv1{ctIn}, decompositionOffset)
+	copy(ctOut.A, res[0].A)
+	copy(ctOut.B, res[0].B)
+}
+
+// CMuxAssign: ctOut = ct0 + ctCond (x) (ct1 - ct0); ctOut may be ct0 (the blind rotation's own use).
+// Reference: evaluator/evaluator.go:85.
+func (e *Evaluator) CMuxAssign(ctCond *trgsw.TRGSWLv1FFT, ct0, ct1 *trlwe.TRLWELv1, decompositionOffset params.Torus, ctOut *trlwe.TRLWELv1) {
+	res := gpu.Scratch().CMuxWith(ctCond, []*trlwe.TRLWELv1{ct0}, []*trlwe.TRLWELv1{ct1}, decompositionOffset)
+	copy(ctOut.A, res[0].A)
+	copy(ctOut.B, res[0].B)
 }
 
 // BlindRotateAssign: the accumulator after all n CMUX steps, into ctOut.  Reference: evaluator/evaluator.go:110.

@@ -313,6 +313,123 @@ func (k *CloudKey) BlindRotateBatch(cts []*tlwe.TLWELv0, testvec *trlwe.TRLWELv1
 	return res
 }
 
+// ---- the trgsw / trlwe seams with caller-supplied operands (include/tfhe_hip.h: tfhe_external_product_with, tfhe_cmux_with,
+// tfhe_sample_extract_batch, tfhe_keyswitch_batch; what shim/go/trgsw, shim/go/trlwe and Evaluator.ExternalProductAssign /
+// CMuxAssign forward to) ----
+
+// DecompositionOffset is cloudkey.CloudKey.DecompositionOffset (cloudkey/cloudkey.go:60-71) as the engine derived it.
+func (k *CloudKey) DecompositionOffset() params.Torus {
+	var off C.uint32_t
+	locked(func() { check(C.tfhe_ctx_decomposition_offset(k.ctx, &off)) })
+	return params.Torus(off)
+}
+
+// flattenTRGSW lays one TRGSWLv1FFT out as [2L][2][N] float64: TRLWEFFT[r].A.Coeffs then .B.Coeffs, the reference's own
+// FourierPoly layout (trgsw/trgsw.go:60-68, poly/poly.go:54-62) -- one element of what UploadKeys flattens n of.
+func flattenTRGSW(g *trgsw.TRGSWLv1FFT, ringN int) []float64 {
+	flat := make([]float64, 0, len(g.TRLWEFFT)*2*ringN)
+	for _, row := range g.TRLWEFFT {
+		if len(row.A.Coeffs) != ringN || len(row.B.Coeffs) != ringN {
+			panic("tfhe_hip: TRGSW row length does not match params.GetTRGSWLv1().N")
+		}
+		flat = append(flat, row.A.Coeffs...)
+		flat = append(flat, row.B.Coeffs...)
+	}
+	if len(flat) != 2*params.GetTRGSWLv1().L*2*ringN {
+		panic("tfhe_hip: TRGSW operand must hold 2*L rows")
+	}
+	return flat
+}
+
+func flattenTRLWE(in []*trlwe.TRLWELv1, ringN int) []params.Torus {
+	flat := make([]params.Torus, 0, len(in)*2*ringN)
+	for _, t := range in {
+		flat = append(flat, flattenTestvec(t, ringN)...)
+	}
+	return flat
+}
+
+func unflattenTRLWE(flat []params.Torus, ringN int) []*trlwe.TRLWELv1 {
+	res := make([]*trlwe.TRLWELv1, len(flat)/(2*ringN))
+	for i := range res {
+		lo := i * 2 * ringN
+		res[i] = &trlwe.TRLWELv1{A: flat[lo : lo+ringN : lo+ringN], B: flat[lo+ringN : lo+2*ringN : lo+2*ringN]}
+	}
+	return res
+}
+
+// ExternalProductWith replaces trgsw.ExternalProductWithFFT / Evaluator.ExternalProductAssign (trgsw/trgsw.go:108-137,
+// evaluator/evaluator.go:50-81) for ANY TRGSW operand: out[i] = g (x) in[i].  Needs no loaded key.
+func (k *CloudKey) ExternalProductWith(g *trgsw.TRGSWLv1FFT, in []*trlwe.TRLWELv1, decompositionOffset params.Torus) []*trlwe.TRLWELv1 {
+	if len(in) == 0 {
+		return []*trlwe.TRLWELv1{}
+	}
+	gf := flattenTRGSW(g, k.ringN)
+	fin := flattenTRLWE(in, k.ringN)
+	out := make([]params.Torus, len(fin))
+	locked(func() {
+		check(C.tfhe_external_product_with(k.ctx, (*C.double)(unsafe.Pointer(&gf[0])), C.uint32_t(decompositionOffset), torusPtr(fin), torusPtr(out), C.int(len(in))))
+	})
+	return unflattenTRLWE(out, k.ringN)
+}
+
+// CMuxWith replaces trgsw.CMUX / Evaluator.CMuxAssign (trgsw/trgsw.go:173-194, evaluator/evaluator.go:85-106):
+// out[i] = ct0[i] + cond (x) (ct1[i] - ct0[i]).
+func (k *CloudKey) CMuxWith(cond *trgsw.TRGSWLv1FFT, ct0, ct1 []*trlwe.TRLWELv1, decompositionOffset params.Torus) []*trlwe.TRLWELv1 {
+	if len(ct0) != len(ct1) {
+		panic("tfhe_hip: operand counts differ")
+	}
+	if len(ct0) == 0 {
+		return []*trlwe.TRLWELv1{}
+	}
+	gf := flattenTRGSW(cond, k.ringN)
+	f0 := flattenTRLWE(ct0, k.ringN)
+	f1 := flattenTRLWE(ct1, k.ringN)
+	out := make([]params.Torus, len(f0))
+	locked(func() {
+		check(C.tfhe_cmux_with(k.ctx, (*C.double)(unsafe.Pointer(&gf[0])), C.uint32_t(decompositionOffset), torusPtr(f0), torusPtr(f1), torusPtr(out), C.int(len(ct0))))
+	})
+	return unflattenTRLWE(out, k.ringN)
+}
+
+// SampleExtract replaces trlwe.SampleExtractIndex (trlwe/trlwe.go:114-128, trlwe/trlwe_ops.go:10-21) for any index.
+func (k *CloudKey) SampleExtract(in []*trlwe.TRLWELv1, index int) []*tlwe.TLWELv1 {
+	res := make([]*tlwe.TLWELv1, len(in))
+	if len(in) == 0 {
+		return res
+	}
+	fin := flattenTRLWE(in, k.ringN)
+	w := k.ringN + 1
+	out := make([]params.Torus, len(in)*w)
+	locked(func() {
+		check(C.tfhe_sample_extract_batch(k.ctx, torusPtr(fin), C.int(index), torusPtr(out), C.int(len(in))))
+	})
+	for i := range res {
+		res[i] = &tlwe.TLWELv1{P: out[i*w : (i+1)*w : (i+1)*w]}
+	}
+	return res
+}
+
+// KeySwitch replaces trgsw.IdentityKeySwitching (trgsw/trgsw.go:285-312, trgsw/keyswitch.go:10-37) on extracted samples.
+func (k *CloudKey) KeySwitch(in []*tlwe.TLWELv1) []*tlwe.TLWELv0 {
+	if len(in) == 0 {
+		return []*tlwe.TLWELv0{}
+	}
+	w := k.ringN + 1
+	fin := make([]params.Torus, 0, len(in)*w)
+	for _, c := range in {
+		if len(c.P) != w {
+			panic("tfhe_hip: TLWELv1 length does not match params.GetTRGSWLv1().N + 1")
+		}
+		fin = append(fin, c.P...)
+	}
+	out := make([]params.Torus, len(in)*k.n1)
+	locked(func() {
+		check(C.tfhe_keyswitch_batch(k.ctx, torusPtr(fin), torusPtr(out), C.int(len(in))))
+	})
+	return unflatten(out, k.n1)
+}
+
 // BootstrapExtendedBatch: a table of ext*N entries (polyExtendFactor = ext: the Uint6/7/8 sets, params/params.go:399-402,
 // which the reference leaves out); lutExt is [ext][2][N] flattened (include/tfhe_hip.h, tfhe_bootstrap_extended_batch).
 func (k *CloudKey) BootstrapExtendedBatch(cts []*tlwe.TLWELv0, lutExt []params.Torus, ext int) []*tlwe.TLWELv0 {
@@ -450,17 +567,39 @@ func (s *CloudKeySet) BootstrapBatch(cts []*tlwe.TLWELv0, testvec *trlwe.TRLWELv
 	return out
 }
 
-// The keys a caller hands to gates.* / evaluator.* are Go pointer graphs; they are uploaded ONCE, on first use, and found
-// again by the identity of the first TRGSW of the bootstrapping key.
+// BlindRotateBatch is CloudKey.BlindRotateBatch over all replicas (trgsw.BatchBlindRotate, trgsw/trgsw.go:234-252).
+func (s *CloudKeySet) BlindRotateBatch(cts []*tlwe.TLWELv0, testvec *trlwe.TRLWELv1) []*trlwe.TRLWELv1 {
+	out := make([]*trlwe.TRLWELv1, len(cts))
+	s.shard(len(cts), func(r *CloudKey, lo, hi int) {
+		copy(out[lo:hi], r.BlindRotateBatch(cts[lo:hi], testvec))
+	})
+	return out
+}
+
+// KeySwitch is CloudKey.KeySwitch over all replicas.
+func (s *CloudKeySet) KeySwitch(in []*tlwe.TLWELv1) []*tlwe.TLWELv0 {
+	out := make([]*tlwe.TLWELv0, len(in))
+	s.shard(len(in), func(r *CloudKey, lo, hi int) {
+		copy(out[lo:hi], r.KeySwitch(in[lo:hi]))
+	})
+	return out
+}
+
+// The keys a caller hands to gates.* / evaluator.* / trgsw.* are Go pointer graphs; they are uploaded ONCE, on first use, and
+// found again by identity: a cloud key by the first TRGSW of its bootstrapping key (and, once seen, the first row of its
+// key-switching key), a key-switching key on its own (trgsw.IdentityKeySwitching) by its first row.
 var registry = struct {
 	sync.Mutex
 	devices []int
 	sets    map[*trgsw.TRGSWLv1FFT]*attachedKey
-}{sets: map[*trgsw.TRGSWLv1FFT]*attachedKey{}}
+	kskOnly map[*tlwe.TLWELv0]*CloudKeySet
+	scratch *CloudKey
+	scratchP C.tfhe_params
+}{sets: map[*trgsw.TRGSWLv1FFT]*attachedKey{}, kskOnly: map[*tlwe.TLWELv0]*CloudKeySet{}}
 
 type attachedKey struct {
-	set    *CloudKeySet
-	hasKSK bool
+	set *CloudKeySet
+	ksk *tlwe.TLWELv0 // identity of the key-switching key loaded beside it (nil: none yet)
 }
 
 // SetDevices chooses the GPUs that keys attached FROM NOW ON are replicated to (nil = every visible GPU).
@@ -470,8 +609,47 @@ func SetDevices(devices []int) {
 	registry.devices = devices
 }
 
+func targetDevices() []int {
+	if len(registry.devices) > 0 {
+		return registry.devices
+	}
+	devices := []int{}
+	for d := 0; d < DeviceCount(); d++ {
+		devices = append(devices, d)
+	}
+	return devices
+}
+
+// adoptSet makes the replica set of a freshly uploaded key: src itself serves its own GPU (no second copy of the keys there,
+// no redundant device-to-device copy) and is cloned GPU to GPU to the others.  If a clone panics, what was made is closed.
+func adoptSet(src *CloudKey, devices []int) *CloudKeySet {
+	s := &CloudKeySet{}
+	ok := false
+	defer func() {
+		if !ok {
+			s.Close()
+			src.Close()
+		}
+	}()
+	used := false
+	for _, d := range devices {
+		if d == src.device && !used {
+			s.replicas = append(s.replicas, src)
+			used = true
+		} else {
+			s.replicas = append(s.replicas, src.CloneTo(d))
+		}
+	}
+	if !used {
+		src.Close()
+	}
+	ok = true
+	return s
+}
+
 // Attached returns the GPU replicas of (bsk, ksk), uploading and replicating them on first use.  ksk may be nil for
-// callers that only blind-rotate; it is loaded into every replica the first time a caller passes it.
+// callers that only blind-rotate; it is loaded into every replica the first time a caller passes it.  A later call with a
+// DIFFERENT key-switching key for the same bootstrapping key panics (two cloud keys cannot share a bootstrapping key).
 func Attached(bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0) *CloudKeySet {
 	if len(bsk) == 0 {
 		panic("tfhe_hip: empty bootstrapping key")
@@ -480,21 +658,63 @@ func Attached(bsk []*trgsw.TRGSWLv1FFT, ksk []*tlwe.TLWELv0) *CloudKeySet {
 	defer registry.Unlock()
 	e, ok := registry.sets[bsk[0]]
 	if !ok {
-		first := 0
-		if len(registry.devices) > 0 {
-			first = registry.devices[0]
+		devices := targetDevices()
+		src := UploadKeys(bsk, ksk, devices[0])
+		e = &attachedKey{set: adoptSet(src, devices)}
+		if ksk != nil {
+			e.ksk = ksk[0]
 		}
-		src := UploadKeys(bsk, ksk, first)
-		e = &attachedKey{set: NewCloudKeySet(src, registry.devices), hasKSK: ksk != nil}
-		src.Close()
 		registry.sets[bsk[0]] = e
-	} else if ksk != nil && !e.hasKSK {
+	} else if ksk != nil && e.ksk == nil {
 		for i := 0; i < e.set.Len(); i++ {
 			e.set.Replica(i).LoadKSK(ksk)
 		}
-		e.hasKSK = true
+		e.ksk = ksk[0]
+	} else if ksk != nil && e.ksk != ksk[0] {
+		panic("tfhe_hip: this bootstrapping key is attached with a different key-switching key")
 	}
 	return e.set
+}
+
+// AttachedKSK returns GPU contexts holding the key-switching key ksk -- the replicas of the cloud key it belongs to when
+// that is attached already, else contexts that hold this key alone (trgsw.IdentityKeySwitching takes nothing else).
+func AttachedKSK(ksk []*tlwe.TLWELv0) *CloudKeySet {
+	if len(ksk) == 0 {
+		panic("tfhe_hip: empty key-switching key")
+	}
+	registry.Lock()
+	defer registry.Unlock()
+	for _, e := range registry.sets {
+		if e.ksk == ksk[0] {
+			return e.set
+		}
+	}
+	s, ok := registry.kskOnly[ksk[0]]
+	if !ok {
+		devices := targetDevices()
+		src := newContext(devices[0])
+		src.LoadKSK(ksk)
+		s = adoptSet(src, devices)
+		registry.kskOnly[ksk[0]] = s
+	}
+	return s
+}
+
+// Scratch is a key-less context of the CURRENT parameter set on the first target GPU, for the operations that take their
+// operands with the call (ExternalProductWith, CMuxWith, SampleExtract).  Re-made when the parameter set has been switched.
+func Scratch() *CloudKey {
+	registry.Lock()
+	defer registry.Unlock()
+	p := currentParams()
+	if registry.scratch != nil && registry.scratchP != p {
+		registry.scratch.Close()
+		registry.scratch = nil
+	}
+	if registry.scratch == nil {
+		registry.scratch = newContext(targetDevices()[0])
+		registry.scratchP = p
+	}
+	return registry.scratch
 }
 
 // Detach releases the GPU replicas of a key.
@@ -507,5 +727,18 @@ func Detach(bsk []*trgsw.TRGSWLv1FFT) {
 	if e, ok := registry.sets[bsk[0]]; ok {
 		e.set.Close()
 		delete(registry.sets, bsk[0])
+	}
+}
+
+// DetachKSK releases the contexts AttachedKSK made for a key-switching key on its own.
+func DetachKSK(ksk []*tlwe.TLWELv0) {
+	if len(ksk) == 0 {
+		return
+	}
+	registry.Lock()
+	defer registry.Unlock()
+	if s, ok := registry.kskOnly[ksk[0]]; ok {
+		s.Close()
+		delete(registry.kskOnly, ksk[0])
 	}
 }

@@ -4,3 +4,6 @@ package poly
 type FourierPoly struct {
 	Coeffs []float64
 }
+
+// Evaluator: opaque here (the shim only passes *poly.Evaluator through, for signature compatibility with trgsw.*).
+type Evaluator struct{}

@@ -22,3 +22,13 @@ func (t *TLWELv0) Neg() *TLWELv0 {
 	}
 	return r
 }
+
+type TLWELv1 struct {
+	P []params.Torus
+}
+
+func NewTLWELv1() *TLWELv1 {
+	return &TLWELv1{P: make([]params.Torus, params.GetTRGSWLv1().N+1)}
+}
+
+func (t *TLWELv1) SetB(val params.Torus) { t.P[len(t.P)-1] = val }

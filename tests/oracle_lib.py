@@ -136,6 +136,26 @@ class Oracle:
         self.lib.orc_external_product(C.byref(p), self.fft(p.N), _f64p(bsk_i), _u32p(ct), _u32p(out))
         return out
 
+    def external_product_at_offset(self, p, gsw, ct, offset):
+        """ExternalProductAssign (evaluator.go:50-81) composed from the restated primitives with an ARBITRARY decomposition offset (the
+        reference takes it as an argument; orc_external_product uses the cloud key's).  gsw: [2L][2][N] float64."""
+        N, L = p.N, p.L
+        rows = np.ascontiguousarray(gsw, np.float64).reshape(2 * L, 2, N)
+        acc = [np.zeros(N, np.float64), np.zeros(N, np.float64)]
+        for part in range(2):
+            digits = np.empty((L, N), np.uint32)
+            self.lib.orc_decompose(C.byref(p), _u32p(np.ascontiguousarray(ct[part])), C.c_uint32(int(offset)), _u32p(digits))
+            for l in range(L):
+                f = self.to_fourier(np.ascontiguousarray(digits[l]))
+                for ab in range(2):
+                    self.lib.orc_fourier_mul_add(N, _f64p(f), _f64p(np.ascontiguousarray(rows[part * L + l, ab])), _f64p(acc[ab]))
+        return np.stack([self.to_poly(acc[0]), self.to_poly(acc[1])])
+
+    def cmux_at_offset(self, p, gsw, ct0, ct1, offset):
+        """CMuxAssign (evaluator.go:85-106) with an arbitrary decomposition offset: ct0 + gsw (x) (ct1 - ct0)."""
+        d = (np.asarray(ct1, np.uint32) - np.asarray(ct0, np.uint32)).astype(np.uint32)
+        return (np.asarray(ct0, np.uint32) + self.external_product_at_offset(p, gsw, d, offset)).astype(np.uint32)
+
     def external_product_exact(self, p, bsk_i_torus, ct):
         out = np.empty((2, p.N), np.uint32)
         self.lib.orc_external_product_exact(C.byref(p), _u32p(bsk_i_torus), _u32p(ct), _u32p(out))

@@ -32,10 +32,10 @@ def _check_sources(files):
 
 
 def _shim_sources(mutate=None):
-    """The three shim packages as extra_sources, optionally with one file's text mutated: {rel path: (old, new)}."""
+    """The five shim packages as extra_sources, optionally with one file's text mutated: {rel path: (old, new)}."""
     mod = "github.com/thedonutfactory/go-tfhe-gpu"
     out = {}
-    for d, fname in (("gpu", "gpu.go"), ("gates", "gates_gpu.go"), ("evaluator", "evaluator_gpu.go")):
+    for d, fname in (("gpu", "gpu.go"), ("gates", "gates_gpu.go"), ("evaluator", "evaluator_gpu.go"), ("trgsw", "trgsw_gpu.go"), ("trlwe", "trlwe_gpu.go")):
         rel = f"shim/go/{d}/{fname}"
         src = _read(rel)
         if mutate and rel in mutate:
@@ -51,7 +51,7 @@ def test_shim_type_checks_against_the_reference_and_the_c_header():
     import gocheck
     errs, stats = gocheck.check_shim(REF, HDR, SHIM)
     assert not errs, "\n".join(errs)
-    assert stats["files"] >= 4 and stats["funcs"] >= 80 and stats["reference_packages"] >= 12, stats
+    assert stats["files"] >= 6 and stats["funcs"] >= 105 and stats["reference_packages"] >= 12, stats
 
 
 @needs_ref
@@ -86,13 +86,14 @@ def test_checker_resolved_the_reference_declarations_the_shim_relies_on():
 
 @needs_ref
 def test_shim_keeps_the_reference_signatures():
-    """gates.* (14 scalar + 6 batch, gates/gates.go:26-126,156-312) and the evaluator's bootstrap surface
-    (evaluator/evaluator.go:110-157, evaluator/programmable_bootstrap.go:16-115, evaluator/gates_helper.go:10-63): every
+    """gates.* (14 scalar + 6 batch, gates/gates.go:26-126,156-312), trgsw.* (trgsw/trgsw.go:108-312, trgsw/keyswitch.go:10),
+    trlwe.SampleExtractIndex[Assign] (trlwe/trlwe.go:114, trlwe/trlwe_ops.go:10) and the evaluator's surface on the path
+    (evaluator/evaluator.go:50-157, evaluator/programmable_bootstrap.go:16-115, evaluator/gates_helper.go:10-63): every
     function of the reference exists in the shim with an IDENTICAL signature (after alias resolution)."""
     import gocheck
     w, ref = gocheck.build_world(REF, HDR)
     shim = {}
-    for d in ("gpu", "gates", "evaluator"):
+    for d in ("gpu", "gates", "evaluator", "trgsw", "trlwe"):
         shim[d], _ = w.load_package(f"github.com/thedonutfactory/go-tfhe-gpu/{d}", gocheck.read_dir(os.path.join(SHIM, d)), name_hint=d, bodies=False)
     for p in ref:
         w.resolve_package(p, strict=False)
@@ -108,7 +109,19 @@ def test_shim_keeps_the_reference_signatures():
         assert w.dealias(shim["gates"].funcs[name]) == w.dealias(rg.funcs[name]), \
             f"gates.{name}: shim {gocheck.tstr(w.dealias(shim['gates'].funcs[name]))} vs reference {gocheck.tstr(w.dealias(rg.funcs[name]))}"
     assert w.dealias(("named", "github.com/thedonutfactory/go-tfhe-gpu/gates.Ciphertext")) == ("named", "github.com/thedonutfactory/go-tfhe/tlwe.TLWELv0")
-    methods = ["BlindRotateAssign", "BootstrapAssign", "Bootstrap", "BootstrapLUTAssign", "BootstrapLUT", "BootstrapLUTTemp", "BootstrapFunc",
+    # SURVEY 8(b) seam 3: the trgsw functions gates.Batch* and the evaluator are built on, and the one trlwe function on the path
+    rt, rl = w.by_path["github.com/thedonutfactory/go-tfhe/trgsw"], w.by_path["github.com/thedonutfactory/go-tfhe/trlwe"]
+    for name in ("ExternalProductWithFFT", "CMUX", "BlindRotate", "BatchBlindRotate", "IdentityKeySwitching", "IdentityKeySwitchingAssign"):
+        assert name in rt.funcs, f"reference trgsw.{name} not found"
+        assert name in shim["trgsw"].funcs, f"shim trgsw.{name} missing"
+        assert w.dealias(shim["trgsw"].funcs[name]) == w.dealias(rt.funcs[name]), \
+            f"trgsw.{name}: shim {gocheck.tstr(w.dealias(shim['trgsw'].funcs[name]))} vs reference {gocheck.tstr(w.dealias(rt.funcs[name]))}"
+    for name in ("SampleExtractIndex", "SampleExtractIndexAssign"):
+        assert name in rl.funcs and name in shim["trlwe"].funcs, name
+        assert w.dealias(shim["trlwe"].funcs[name]) == w.dealias(rl.funcs[name]), f"trlwe.{name}: signature differs"
+    assert w.dealias(("named", "github.com/thedonutfactory/go-tfhe-gpu/trgsw.TRGSWLv1FFT")) == ("named", "github.com/thedonutfactory/go-tfhe/trgsw.TRGSWLv1FFT")
+    assert w.dealias(("named", "github.com/thedonutfactory/go-tfhe-gpu/trlwe.TRLWELv1")) == ("named", "github.com/thedonutfactory/go-tfhe/trlwe.TRLWELv1")
+    methods = ["ExternalProductAssign", "CMuxAssign", "BlindRotateAssign", "BootstrapAssign", "Bootstrap", "BootstrapLUTAssign", "BootstrapLUT", "BootstrapLUTTemp", "BootstrapFunc",
                "BootstrapFuncAssign", "PrepareNAND", "PrepareAND", "PrepareOR", "PrepareXOR"]
     for m in methods:
         assert ("Evaluator", m) in re_.methods, f"reference Evaluator.{m} not found"
@@ -150,6 +163,13 @@ MUTATIONS = [
     ("shim/go/gates/gates_gpu.go", "\t\tout.SetB(eighth)\n", "\t\tout.SetB(0.125)\n", "cannot use untyped float"),
     ("shim/go/evaluator/evaluator_gpu.go", "e.BootstrapAssign(ctIn, lut.Poly, bsk, ksk, decompositionOffset, ctOut)", "e.BootstrapAssign(ctIn, lut, bsk, ksk, decompositionOffset, ctOut)", "cannot use"),
     ("shim/go/evaluator/evaluator_gpu.go", "copy(ctOut.P, res[0].P)", "copy(ctOut.P, res[0].A)", "has no field or method A"),
+    ("shim/go/trgsw/trgsw_gpu.go", "return gpu.Scratch().CMuxWith(cond, []*trlwe.TRLWELv1{in1}, []*trlwe.TRLWELv1{in2}, decompositionOffset)[0]",
+     "return gpu.Scratch().CMuxWith(in1, []*trlwe.TRLWELv1{in1}, []*trlwe.TRLWELv1{in2}, decompositionOffset)[0]", "cannot use"),
+    ("shim/go/trgsw/trgsw_gpu.go", "return gpu.AttachedKSK(keySwitchingKey).Pick().KeySwitch([]*tlwe.TLWELv1{src})[0]",
+     "return gpu.AttachedKSK(keySwitchingKey).Pick().KeySwitch([]*tlwe.TLWELv0{src})[0]", "cannot use"),
+    ("shim/go/trlwe/trlwe_gpu.go", "copy(output.P, SampleExtractIndex(trlwe, k).P)", "copy(output.P, SampleExtractIndex(trlwe, k).A)", "has no field or method A"),
+    ("shim/go/gpu/gpu.go", "check(C.tfhe_keyswitch_batch(k.ctx, torusPtr(fin), torusPtr(out), C.int(len(in))))", "check(C.tfhe_keyswitch_batch(k.ctx, torusPtr(fin), torusPtr(out)))", "argument(s) for 4 parameter(s)"),
+    ("shim/go/gpu/gpu.go", "C.uint32_t(decompositionOffset), torusPtr(fin), torusPtr(out), C.int(len(in))))", "decompositionOffset, torusPtr(fin), torusPtr(out), C.int(len(in))))", "cannot use"),
     ("shim/go/evaluator/evaluator_gpu.go", "lookupTable := generator.GenLookUpTable(f)\n\treturn", "lookupTable := generator.GenLookupTable(f)\n\treturn", "has no field or method GenLookupTable"),
 ]
 
@@ -233,6 +253,10 @@ def test_go_stubs_declare_what_the_reference_declares():
         rp = saved[f"{mod}/{d}"]
         for name, (kind, t) in sp.types.items():
             assert name in rp.types, f"{d}.{name} is not a type of the reference"
+            if kind == "defined" and t == ("struct", ()):          # an OPAQUE stub (passed through by pointer only): the reference must have a struct of that name
+                assert rp.types[name][0] == "defined" and rp.types[name][1][0] == "struct", f"{d}.{name}: not a struct in the reference"
+                checked += 1
+                continue
             assert rp.types[name][0] == kind and norm(t) == norm(rp.types[name][1]), f"{d}.{name}: stub {t} vs reference {rp.types[name][1]}"
             checked += 1
         for name, ft in sp.funcs.items():
@@ -244,13 +268,18 @@ def test_go_stubs_declare_what_the_reference_declares():
     assert checked >= 20, checked
 
 
-def test_integration_md_shows_the_shim_files_verbatim():
+def test_integration_md_names_every_shim_file_and_its_one_block_is_verbatim():
+    # INTEGRATION.md points at the shim files (it used to inline three of them: 850 lines kept in sync by hand); the one file it does
+    # show must equal the file, and every shim file must be named
     import sync_integration_md as sync
     doc = _read("INTEGRATION.md")
     found = dict(sync.blocks(doc))
-    for rel in ("shim/go/gpu/gpu.go", "shim/go/gates/gates_gpu.go", "shim/go/evaluator/evaluator_gpu.go"):
-        assert rel in found, f"INTEGRATION.md has no block for {rel}"
-        assert found[rel] == sync.render(rel), f"INTEGRATION.md's block for {rel} differs from the file: run python tools/go_static/sync_integration_md.py"
+    assert found, "INTEGRATION.md shows no shim file"
+    for rel, body in found.items():
+        assert body == sync.render(rel), f"INTEGRATION.md's block for {rel} differs from the file: run python tools/go_static/sync_integration_md.py"
+    for d in sorted(os.listdir(SHIM)):
+        for f in sorted(os.listdir(os.path.join(SHIM, d))) if os.path.isdir(os.path.join(SHIM, d)) else []:
+            assert f"shim/go/{d}/{f}" in doc or (f in doc and f"shim/go/{d}/" in doc), f"INTEGRATION.md does not mention shim/go/{d}/{f}"
 
 
 def test_shim_calls_every_entry_point_with_the_declared_argument_count():
@@ -279,8 +308,8 @@ def test_shim_calls_every_entry_point_with_the_declared_argument_count():
         assert name in decl, f"gpu.go calls undeclared {name}"
         assert n == decl[name], f"{name}: shim passes {n} arguments, header declares {decl[name]}"
         calls.add(name)
-    assert len(calls) >= 15, sorted(calls)
-    for other in ("shim/go/gates/gates_gpu.go", "shim/go/evaluator/evaluator_gpu.go"):
+    assert len(calls) >= 20, sorted(calls)
+    for other in ("shim/go/gates/gates_gpu.go", "shim/go/evaluator/evaluator_gpu.go", "shim/go/trgsw/trgsw_gpu.go", "shim/go/trlwe/trlwe_gpu.go"):
         assert 'import "C"' not in _read(other), f"{other} must not touch cgo: package gpu is the only cgo layer"
 
 
@@ -298,4 +327,4 @@ def test_recorded_run_of_the_shims_own_go_test():
     for name, t in rec["tests"].items():
         assert t["failures"] == [] and not t["skipped"] and t["statements"] > 10**6, (name, t)
     assert rec["c_abi_calls"]["gate_batch"] == 60 and rec["c_abi_calls"]["load_bsk"] == 3
-    assert rec["contexts_created"] == 9 and rec["contexts_alive_at_end"] == 0
+    assert rec["contexts_created"] == 6 and rec["contexts_alive_at_end"] == 0           # per test: one upload (serves device 0) + one clone

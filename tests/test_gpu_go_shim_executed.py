@@ -42,7 +42,7 @@ def world(request, pkg, oracle, keys_small):
     ck = gi.GoPtr(gi.GoStruct(I.named(T["cloudkey"], "CloudKey"), {
         "DecompositionOffset": np.uint32(oracle.offset(k.p)), "BlindRotateTestvec": tv,
         "KeySwitchingKey": gi.GoSlice(ksk, 0, len(ksk), len(ksk), None), "BootstrappingKey": gi.GoSlice(bsk, 0, len(bsk), len(bsk), None)}))
-    shim = {n: I.pkg_by_import(f"{MOD}/{n}") for n in ("gpu", "gates", "evaluator")}
+    shim = {n: I.pkg_by_import(f"{MOD}/{n}") for n in ("gpu", "gates", "evaluator", "trgsw", "trlwe")}
 
     def call(p, fn, *a):
         I.ensure_init(shim[p])
@@ -50,7 +50,12 @@ def world(request, pkg, oracle, keys_small):
     # two contexts on the one GPU of the box: the registry uploads once and replicates with tfhe_ctx_clone_to (device-to-device here)
     call("gpu", "SetDevices", gi.GoSlice([0, 0], 0, 2, 2, gi.BASIC_RT["int"]))
     words = lambda ct: gi.slice_to_np(ct.v.f["P"], np.uint32)                                                    # noqa: E731
-    yield dict(I=I, gi=gi, mock=mock, ck=ck, lwe=lwe, call=call, words=words, k=k, o=oracle)
+    def trl(arr):                                                             # [2][N] words -> *trlwe.TRLWELv1
+        return gi.GoPtr(gi.GoStruct(I.named(T["trlwe"], "TRLWELv1"), {"A": torus(arr[0]), "B": torus(arr[1])}))
+
+    def trl_words(t):
+        return np.stack([gi.slice_to_np(t.v.f["A"], np.uint32), gi.slice_to_np(t.v.f["B"], np.uint32)])
+    yield dict(I=I, gi=gi, mock=mock, ck=ck, lwe=lwe, call=call, words=words, k=k, o=oracle, bsk=bsk, trl=trl, trl_words=trl_words, T=T, torus=torus)
     call("gates", "Release", ck)
 
 
@@ -65,9 +70,9 @@ def test_the_shims_gates_drive_the_gpu_and_match_the_oracle(world):
     assert np.array_equal(got, o.gate(k.p, k.bsk, k.ksk, "MUX", a[1], b[1], c[1]))
     calls = w["mock"].calls
     names = [x[0] for x in calls]
-    assert names.count("load_bsk") == 1 and names.count("load_ksk") == 1 and names.count("clone_to") == 2
+    assert names.count("load_bsk") == 1 and names.count("load_ksk") == 1 and names.count("clone_to") == 1
     live = [x for x in w["mock"].ctxs if x is not None]
-    assert [x["clone_path"] for x in live] == [1, 1]                               # both replicas: device-to-device clones (TFHE_OPT_CLONE_PATH)
+    assert [x["clone_path"] for x in live] == [0, 1]                               # the upload serves the GPU itself; the second context is a device-to-device clone (TFHE_OPT_CLONE_PATH)
     assert sum(1 for x in calls if x[0] == "gate_batch") == 11
 
 
@@ -103,6 +108,52 @@ def test_the_shims_evaluator_bootstraps_on_the_gpu(world):
     want = o.blind_rotate(k.p, k.bsk, w["words"](prep), k.tv)
     gi = w["gi"]
     assert np.array_equal(gi.slice_to_np(acc.v.f["A"], np.uint32), want[0]) and np.array_equal(gi.slice_to_np(acc.v.f["B"], np.uint32), want[1])
+
+
+def test_the_shims_trgsw_and_trlwe_seams_on_the_gpu(world):
+    """SURVEY 8(b) seam 3 through the Go files: trgsw.ExternalProductWithFFT / CMUX (a free-standing TRGSW operand travels with the call),
+    BlindRotate / BatchBlindRotate (sharded over the two contexts), trlwe.SampleExtractIndex, trgsw.IdentityKeySwitching[Assign],
+    Evaluator.ExternalProductAssign / CMuxAssign -- executed by the interpreter, every C.tfhe_* call into the library, results == oracle."""
+    w = world
+    I, gi, k, o = w["I"], w["gi"], w["k"], w["o"]
+    ckf = w["ck"].v.f
+    off, tv = ckf["DecompositionOffset"], ckf["BlindRotateTestvec"]
+    rs = np.random.RandomState(81)
+    r = lambda: rs.randint(0, 2**32, size=(2, k.p.N), dtype=np.uint64).astype(np.uint32)                        # noqa: E731
+    x0, x1 = r(), r()
+    gsw = w["bsk"][5]
+    got = w["call"]("trgsw", "ExternalProductWithFFT", gsw, w["trl"](x0), off, None)
+    assert np.array_equal(w["trl_words"](got), o.external_product(k.p, k.bsk[5], x0))
+    got = w["call"]("trgsw", "CMUX", w["trl"](x0), w["trl"](x1), gsw, off, None)
+    assert np.array_equal(w["trl_words"](got), o.cmux(k.p, k.bsk[5], x0, x1))
+    ev = w["call"]("evaluator", "NewEvaluator", int(k.p.N))
+    out = I.call_func("trlwe", "NewTRLWELv1")
+    I.call_method(ev, "ExternalProductAssign", gsw, w["trl"](x1), off, out)
+    assert np.array_equal(w["trl_words"](out), o.external_product(k.p, k.bsk[5], x1))
+    acc = w["trl"](x0.copy())
+    I.call_method(ev, "CMuxAssign", gsw, acc, w["trl"](x1), off, acc)                  # ctOut == ct0
+    assert np.array_equal(w["trl_words"](acc), o.cmux(k.p, k.bsk[5], x0, x1))
+    cts = k.enc([1, 0, 1, 1, 0])
+    srcs = gi.GoSlice([w["lwe"](c) for c in cts], 0, 5, 5, None)
+    before = len(w["mock"].calls)
+    res = w["call"]("trgsw", "BatchBlindRotate", srcs, tv, ckf["BootstrappingKey"], off)
+    for i in range(5):
+        assert np.array_equal(w["trl_words"](res.a[res.o + i]), o.blind_rotate(k.p, k.bsk, cts[i], k.tv)), i
+    assert sorted(x[2] for x in w["mock"].calls[before:] if x[0] == "blind_rotate_batch") == [2, 3]
+    one = w["call"]("trgsw", "BlindRotate", w["lwe"](cts[2]), tv, ckf["BootstrappingKey"], off, None)
+    assert np.array_equal(w["trl_words"](one), w["trl_words"](res.a[res.o + 2]))
+    with pytest.raises(gi.GoPanic, match="decompositionOffset"):
+        w["call"]("trgsw", "BlindRotate", w["lwe"](cts[2]), tv, ckf["BootstrappingKey"], np.uint32(3), None)
+    a0 = w["trl_words"](res.a[res.o])
+    for idx in (0, 9, k.p.N - 1):
+        e = w["call"]("trlwe", "SampleExtractIndex", res.a[res.o], idx)
+        assert np.array_equal(gi.slice_to_np(e.v.f["P"], np.uint32), o.sample_extract(np.ascontiguousarray(a0), idx)), idx
+    ext = w["call"]("trlwe", "SampleExtractIndex", res.a[res.o], 0)
+    lv0 = w["call"]("trgsw", "IdentityKeySwitching", ext, ckf["KeySwitchingKey"])
+    assert np.array_equal(w["words"](lv0), o.key_switch(k.p, k.ksk, o.sample_extract(np.ascontiguousarray(a0), 0)))
+    assert np.array_equal(w["words"](lv0), o.bootstrap(k.p, k.bsk, k.ksk, cts[0], k.tv))                       # == the whole bootstrap
+    names = [x[0] for x in w["mock"].calls[before:]]
+    assert names.count("load_ksk") == 0 and names.count("load_bsk") == 0          # the key switch ran on the cloud key's own replicas
 
 
 def test_a_library_error_reaches_go_as_a_panic(world):

@@ -48,35 +48,19 @@ def test_external_product_with_any_operand_bit_exact(pkg, oracle, keys_small, ck
         blank.close()
 
 
-def oracle_external_product_at_offset(o, p, gsw, ct, offset):
-    """ExternalProductAssign (evaluator.go:50-81) composed from the oracle's primitives with an arbitrary decomposition offset."""
-    import ctypes as C
-    from oracle_lib import _u32p
-    N, L = p.N, p.L
-    acc = [np.zeros(N, np.float64), np.zeros(N, np.float64)]
-    for part in range(2):
-        digits = np.empty((L, N), np.uint32)
-        o.lib.orc_decompose(C.byref(p), _u32p(np.ascontiguousarray(ct[part])), C.c_uint32(offset), _u32p(digits))
-        for l in range(L):
-            f = o.to_fourier(np.ascontiguousarray(digits[l]))
-            row = gsw.reshape(2 * L, 2, N)[part * L + l]
-            for ab in range(2):
-                o.lib.orc_fourier_mul_add(N, f.ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(row[ab]).ctypes.data_as(C.POINTER(C.c_double)),
-                                          acc[ab].ctypes.data_as(C.POINTER(C.c_double)))
-    return np.stack([o.to_poly(acc[0]), o.to_poly(acc[1])])
-
-
 def test_external_product_with_a_callers_own_offset(pkg, oracle, keys_small, ck_small):
     # the reference passes decompositionOffset as an argument (trgsw.go:108, evaluator.go:50): any value is a kernel operand here
     k = keys_small
     rs = np.random.RandomState(32)
     trl = trlwe_batch(rs, 3, k.p.N)
     std = oracle.offset(k.p)
-    assert np.array_equal(oracle_external_product_at_offset(oracle, k.p, k.bsk[2], trl[0], std), oracle.external_product(k.p, k.bsk[2], trl[0]))
+    assert np.array_equal(oracle.external_product_at_offset(k.p, k.bsk[2], trl[0], std), oracle.external_product(k.p, k.bsk[2], trl[0]))
     for off in (0, 0x12345678, std ^ 0x80000000):
         got = ck_small.ctx.external_product_with(k.bsk[2], trl, offset=off)
+        cm = ck_small.ctx.cmux_with(k.bsk[2], trl, trl[::-1].copy(), offset=off)
         for b in range(3):
-            assert np.array_equal(got[b], oracle_external_product_at_offset(oracle, k.p, k.bsk[2], trl[b], off)), (off, b)
+            assert np.array_equal(cm[b], oracle.cmux_at_offset(k.p, k.bsk[2], trl[b], trl[2 - b], off)), (off, b)
+            assert np.array_equal(got[b], oracle.external_product_at_offset(k.p, k.bsk[2], trl[b], off)), (off, b)
 
 
 def test_cmux_with_selects_and_is_bit_exact(pkg, oracle, keys_small, ck_small):

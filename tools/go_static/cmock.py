@@ -67,6 +67,23 @@ class OracleBackend:
     def gate_testvec(self, p):
         return self.o.gate_testvec(p)
 
+    def offset(self, h, p):
+        return self.o.offset(p)
+
+    def external_product_with(self, h, p, gsw, off, X):
+        return np.stack([self.o.external_product_at_offset(p, gsw, X[i], off) for i in range(len(X))])
+
+    def cmux_with(self, h, p, gsw, off, X0, X1):
+        return np.stack([self.o.cmux_at_offset(p, gsw, X0[i], X1[i], off) for i in range(len(X0))])
+
+    def sample_extract(self, h, p, X, k):
+        return np.stack([self.o.sample_extract(np.ascontiguousarray(X[i]), int(k)) for i in range(len(X))])
+
+    def keyswitch(self, h, p, X):
+        if h["ksk"] is None:
+            raise MockError(-2, "key-switching key not loaded")
+        return np.stack([self.o.key_switch(p, h["ksk"], np.ascontiguousarray(X[i])) for i in range(len(X))])
+
 
 class LibBackend:
     """The REAL library: every entry point goes to libtfhe_hip.so through the Python binding's ctypes layer (go-tfhe_amd/_binding.py), i.e.
@@ -120,6 +137,21 @@ class LibBackend:
 
     def keygen(self, h, p, s0, s1, a0, a1):
         self._wrap(lambda: h.keygen_cloud(s0, s1, a0, a1, None))
+
+    def offset(self, h, p):
+        return self._wrap(lambda: h.decomposition_offset())
+
+    def external_product_with(self, h, p, gsw, off, X):
+        return self._wrap(lambda: h.external_product_with(gsw, X, off))
+
+    def cmux_with(self, h, p, gsw, off, X0, X1):
+        return self._wrap(lambda: h.cmux_with(gsw, X0, X1, off))
+
+    def sample_extract(self, h, p, X, k):
+        return self._wrap(lambda: h.sample_extract_batch(X, int(k)))
+
+    def keyswitch(self, h, p, X):
+        return self._wrap(lambda: h.keyswitch_batch(X))
 
     def key_size(self, h, which):
         return self._wrap(lambda: h.key_size(which))
@@ -324,6 +356,53 @@ class MockC:
         T = self.be.gate_testvec(p) if tv is None else self.read(tv, 2 * p.N, np.uint32).reshape(2, p.N)
         self.write(out, self.be.blind_rotate_batch(c["h"], p, X, T, int(nsteps)))
         self.calls.append(("blind_rotate_batch", c["device"], B))
+        return 0
+
+
+    # ---- the trgsw / trlwe seams with caller-supplied operands
+    def tfhe_ctx_decomposition_offset(self, h, out):
+        c = self.ctx(h)
+        gi.ptr_store(out, np.uint32(self.be.offset(c["h"], c["p"])))
+        return 0
+
+    def _gsw(self, p, ptr):
+        if ptr is None:
+            raise MockError(-1, "null TRGSW operand")
+        return self.read(ptr, 2 * p.L * 2 * p.N, np.float64).reshape(2 * p.L, 2, p.N)
+
+    def tfhe_external_product_with(self, h, gsw, off, inp, out, B):
+        c = self.ctx(h)
+        p, B = c["p"], int(B)
+        X = self.read(inp, B * 2 * p.N, np.uint32).reshape(B, 2, p.N)
+        self.write(out, self.be.external_product_with(c["h"], p, self._gsw(p, gsw), int(off), X))
+        self.calls.append(("external_product_with", c["device"], B))
+        return 0
+
+    def tfhe_cmux_with(self, h, gsw, off, ct0, ct1, out, B):
+        c = self.ctx(h)
+        p, B = c["p"], int(B)
+        X0 = self.read(ct0, B * 2 * p.N, np.uint32).reshape(B, 2, p.N)
+        X1 = self.read(ct1, B * 2 * p.N, np.uint32).reshape(B, 2, p.N)
+        self.write(out, self.be.cmux_with(c["h"], p, self._gsw(p, gsw), int(off), X0, X1))
+        self.calls.append(("cmux_with", c["device"], B))
+        return 0
+
+    def tfhe_sample_extract_batch(self, h, inp, k, out, B):
+        c = self.ctx(h)
+        p, B = c["p"], int(B)
+        if not 0 <= int(k) < p.N:
+            raise MockError(-1, f"sample-extract index {k} outside [0, {p.N})")
+        X = self.read(inp, B * 2 * p.N, np.uint32).reshape(B, 2, p.N)
+        self.write(out, self.be.sample_extract(c["h"], p, X, int(k)))
+        self.calls.append(("sample_extract_batch", c["device"], B))
+        return 0
+
+    def tfhe_keyswitch_batch(self, h, inp, out, B):
+        c = self.ctx(h)
+        p, B = c["p"], int(B)
+        X = self.read(inp, B * (p.N + 1), np.uint32).reshape(B, p.N + 1)
+        self.write(out, self.be.keyswitch(c["h"], p, X))
+        self.calls.append(("keyswitch_batch", c["device"], B))
         return 0
 
 
