@@ -616,6 +616,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sustained-steps", type=int, default=1000,
+                    help="after the K timed steps: this many further steps (~6 s) with the clock / power sampler running, reported as "
+                         "timed_window.sustained -- the figure a long run gets, measured by THIS run on THIS box (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3/4/5 and the ceiling micro-benchmarks after the headline")
     ap.add_argument("--no-live-pmc", action="store_true", help="report the committed rocprofv3 PMC passes instead of collecting FETCH_SIZE / WRITE_SIZE in this run")
@@ -748,8 +751,38 @@ def main():
     br_n, br_ms = ctx.timing_read(0)
     ks_n, ks_ms = ctx.timing_read(1)
 
+    # ---- the sustained figure, measured by THIS run (round 5 quoted a committed one from another box: the kernel is power-limited and the
+    # box's silicon decides the clock, so the two differed by 8 % on the driver's box).  The K-step window above is the contractual
+    # `value`; these further steps only say what a long run gets on this box, with clock and power sampled throughout.
+    got = out.cpu().numpy().view(np.uint32).copy()       # what the K timed steps wrote (checked below), before anything else touches `out`
+    sustained = None
+    if args.sustained_steps > 0:
+        out.zero_()
+        torch.cuda.synchronize()
+        s_sampler = telemetry.Sampler(local_rank, period_s=0.02)
+        barrier()
+        torch.cuda.synchronize()
+        with s_sampler:
+            ts0 = time.perf_counter()
+            for _ in range(args.sustained_steps):
+                step()
+            torch.cuda.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            s_elapsed = time.perf_counter() - ts0
+        s_ok = bool(np.array_equal(key.dec(out.cpu().numpy().view(np.uint32)), ~(bits_a.astype(bool) & bits_b.astype(bool))))
+        if dist:
+            st = torch.tensor([s_elapsed, 0.0 if s_ok else 1.0], dtype=torch.float64)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            s_elapsed, s_ok = float(st[0].item()), float(st[1].item()) == 0.0
+        tel = s_sampler.summary()
+        sustained = {"steps": args.sustained_steps, "seconds": s_elapsed, "ms_per_step": s_elapsed * 1e3 / args.sustained_steps,
+                     "value": world * BATCH * args.sustained_steps / s_elapsed, "unit": "gates/s", "verified": s_ok,
+                     "sclk_mhz_mean": tel.get("sclk_mhz_mean"), "power_w_mean": tel.get("power_w_mean"), "telemetry_rank0": tel,
+                     "how": "measured by this run, right after the timed window: back-to-back steps of the same workload, all-ranks barrier at both "
+                            "ends, max over ranks; every output of the last step decrypts to NAND of its inputs"}
+
     # ---- after the timed region: is what it computed right?
-    got = out.cpu().numpy().view(np.uint32)
     dec_ok = bool(np.array_equal(key.dec(got), ~(bits_a.astype(bool) & bits_b.astype(bool))))
     sample = [0, BATCH // 2 + 1, BATCH - 1]
     if key.bsk is not None:                              # the rank that built the host key re-does three gates on the oracle
@@ -821,11 +854,14 @@ def main():
                              "sample": sample, "of": "the output buffer the last timed step wrote (zeroed before the timed region)"},
             "init": f"{INIT_LAUNCHES} untimed context-initialisation launches (scratch first touch, clock ramp) before the {args.warmup} warm-up steps",
             "timed_window": {"seconds": elapsed,
-                             "note": "the blind rotate runs power-limited (~1.34 kW, ~2.24 GHz sustained); a default 20-step window lasts ~0.11 s, which is "
-                                     "SHORTER than the board's power / clock ramp -- `telemetry` shows the power still rising inside it -- so this figure is "
-                                     "taken at a slightly higher clock than a long run gets; the sustained figure (python bench.py --steps 3000, ~16 s of "
-                                     "back-to-back launches, same verification) is committed beside it and agrees within 2 %",
-                             "sustained_run": SUSTAINED_RUN},
+                             "note": "the blind rotate runs power-limited (~1.3 kW); a default 20-step window lasts ~0.11 s, which is SHORTER than the "
+                                     "board's power / clock ramp (`telemetry` shows the power still rising inside it) and carries one barrier per 20 "
+                                     "steps, so `value` can sit a per cent or two on either side of what a long run gets.  `sustained` is the long "
+                                     "run ON THIS BOX, measured by this run with clock and power sampled; the committed figure of another box is kept "
+                                     "for comparison only (box silicon decides the clock)",
+                             "sustained": sustained,
+                             "sustained_over_value": (sustained["value"] / value) if sustained else None,
+                             "committed_for_comparison": SUSTAINED_RUN},
             "kernels": {"k_blind_rotate_ms": br_avg_ms, "keyswitch_ms": ks_avg_ms,
                         "keyswitch_kernels": "k_ks_init + k_ks_onehot + k_keyswitch_mfma (exact int8 matrix-core product, csrc/keyswitch_mfma.hpp)",
                         "keyswitch_int8_Tops": 2.0 * BATCH * 4 * (p.n + 1) * (p.N * p.t * 4) / (ks_avg_ms * 1e-3) / 1e12 if ks_n else None,

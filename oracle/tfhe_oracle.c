@@ -1,18 +1,18 @@
 /*
  * tfhe_oracle.c -- CPU restatement of go-tfhe's gate-bootstrap hot path (plain C).
  *
- * TEST INFRASTRUCTURE ONLY (see tfhe_oracle.h).  How it is pinned: the Go reference holds no
- * golden vectors for this path and the image has no Go toolchain, so no Go BINARY has ever
- * produced a vector for it ("parity unpinned" in that sense: tests/test_go_golden.py skips).
- * Since round 5 the reference's own SOURCE TEXT is executed here instead -- by
- * tools/go_static/gointerp.py, a Go-subset interpreter that knows nothing about TFHE -- and
- * this restatement is held, bit for bit, to what the reference's functions computed
- * (tests/golden/goref/, tests/test_goref_vectors.py: transforms incl. their fp64 spectra,
- * decomposition, rotation, key ingest, external product, CMUX, blind rotation, key switch,
- * whole bootstraps and every gate at the full 128-bit set, lookup tables, Uint5 programmable
- * bootstraps, and the reference's own key generation / encryption / decryption at a reduced
- * LWE dimension), next to the reference's decrypt-level tests / KATs and the exact-integer
- * product below.
+ * TEST INFRASTRUCTURE ONLY (see tfhe_oracle.h).
+ *
+ * PARITY UNPINNED by the Go toolchain.  The reference is pure Go, holds no golden vectors for this
+ * path, and the image has no Go toolchain: no Go binary has ever produced a vector for it, there is
+ * no oracle/_ref, and tests/test_go_golden.py skips (tools/go_golden/README.md: the three commands
+ * that turn it green).  What this restatement IS held to: the reference's only numeric known answer
+ * and its decrypt-level truth tables (tests/test_oracle_pins.py), the FFT-free exact-integer product
+ * below (at N = 1024, L = 3 any correct fp64 FFT must give these words), and -- CORROBORATION, not a
+ * pin -- the reference's source text executed under an in-repo interpreter
+ * (tools/go_static/gointerp.py: a Go-subset executor written for this repository, with stand-ins for
+ * math/cmplx (libc), math/rand (numpy) and goroutines (inlined); tests/golden/goref/,
+ * tests/test_goref_vectors.py: bit for bit up to whole bootstraps and every gate at the full 128-bit set).
  *
  * Build with -ffp-contract=off: Go on amd64 never fuses a*b+c, and the reference's
  * complex arithmetic is written as separate multiplies and adds.

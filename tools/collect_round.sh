@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
-( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --no-cpu-baseline --no-configs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err )
+( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $R/bench.py --no-cpu-baseline --no-configs --sustained-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err )
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_u5 -- python $R/tools/pmc_workload.py uint5 512 12 > $OUT/u5_under_rocprof.log 2>&1 )
 find $OUT/stats_u5 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_uint5.csv \;
