@@ -108,7 +108,7 @@ def case_exact(rs, o, K, log):
     import torch
     p, ctx = K.p, K.ctx
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    kind = rs.choice(["gate1", "gates", "gates_dev", "pbs", "pbs_items", "rotate_ks", "threads"], p=[.2, .25, .15, .1, .1, .12, .08])
+    kind = rs.choice(["gate1", "gates", "gates_dev", "pbs", "pbs_items", "rotate_ks", "threads", "seams"], p=[.18, .22, .14, .1, .1, .1, .08, .08])
     B = pick_batch(rs, cus, heavy=p.n > 40)
     if p.n > 100:
         B = min(B, 300)                          # a full-size set: the oracle is the clock
@@ -118,6 +118,8 @@ def case_exact(rs, o, K, log):
         log.append("on-a-clone")
     set_options(rs, ctx, log)
     n1 = p.n + 1
+    if kind == "seams":
+        return seams(rs, o, K, ctx, min(B, 200), log, exact=True)
     if kind == "threads":
         # concurrent callers of the host-pointer entry point (flat combining): every caller must get what a lone call gets
         import threading
@@ -214,6 +216,43 @@ def case_exact(rs, o, K, log):
     for i in rs.choice(B, size=min(B, 64), replace=False):
         if not np.array_equal(got[i], o.key_switch(p, K.ksk, o.sample_extract(trl[i]))):
             return False, f"key switch {i} differs"
+    return True, ""
+
+
+def seams(rs, o, K, ctx, B, log, exact):
+    """The trgsw / trlwe seams with caller-supplied operands (round 6: tfhe_external_product_with, tfhe_cmux_with, tfhe_sample_extract_batch,
+    tfhe_keyswitch_batch): a TRGSW operand handed over free-standing, the caller's own decomposition offset, any extraction index.
+    exact: word equality with the oracle (N = 1024, L = 3); else one product within the stated 2^9 words of the oracle's fp64 product at the
+    cloud key's offset, the integer seams exact as everywhere."""
+    p = K.p
+    j = int(rs.randint(p.n))
+    std = o.offset(p)
+    off = std if (not exact or rs.rand() < 0.6) else int(rs.randint(0, 2**32, dtype=np.uint64))
+    log.append(f"gsw={j} off={'std' if off == std else hex(off)}")
+    t0, t1 = words(rs, (B, 2, p.N)), words(rs, (B, 2, p.N))
+    ep = ctx.external_product_with(K.bsk[j], t0, offset=off)
+    cm = ctx.cmux_with(K.bsk[j], t0, t1, offset=off)
+    for i in rs.choice(B, size=min(B, 6), replace=False):
+        we, wc = o.external_product_at_offset(p, K.bsk[j], t0[i], off), o.cmux_at_offset(p, K.bsk[j], t0[i], t1[i], off)
+        if exact:
+            if not np.array_equal(ep[i], we) or not np.array_equal(cm[i], wc):
+                return False, f"external product / CMUX {i} with a free-standing operand differs"
+        else:
+            for got, want in ((ep[i], we), (cm[i], wc)):
+                e = (got.astype(np.int64) - want.astype(np.int64)) % 2**32
+                if int(np.minimum(e, 2**32 - e).max()) > 2**9:
+                    return False, f"external product / CMUX {i} more than 2^9 words from the oracle's"
+    k = int(rs.choice([0, 1, p.N - 1, rs.randint(p.N)]))
+    log.append(f"k={k}")
+    ext = ctx.sample_extract_batch(t0, k)
+    for i in rs.choice(B, size=min(B, 16), replace=False):
+        if not np.array_equal(ext[i], o.sample_extract(np.ascontiguousarray(t0[i]), k)):
+            return False, f"sample extract {i} at index {k} differs"
+    lwe1 = edge_rows(rs, words(rs, (B, p.N + 1)))
+    ks = ctx.keyswitch_batch(lwe1)
+    for i in rs.choice(B, size=min(B, 24), replace=False):
+        if not np.array_equal(ks[i], o.key_switch(p, K.ksk, lwe1[i])):
+            return False, f"key switch of extracted sample {i} differs"
     return True, ""
 
 
@@ -361,6 +400,10 @@ def case_uint(rs, o, K, log):
     for i in rs.choice(B, size=min(B, 32), replace=False):
         if not np.array_equal(got[i], o.key_switch(p, K.ksk, o.sample_extract(trl[i]))):
             return False, f"key switch {i} differs"
+    if rs.rand() < 0.2:
+        ok, why = seams(rs, o, K, ctx, min(B, 40), log, exact=False)
+        if not ok:
+            return ok, why
     table = rs.randint(0, m, m)
     tv = o.lut_generate(p, [int(x) for x in table])
     msgs = rs.randint(0, m, B)

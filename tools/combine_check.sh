@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/r06_combine_check.sh <tag>: the lock-free combiner and the seam entry points on the GPU box -- tests, the concurrent-submitter
+# tools/combine_check.sh <tag>: the lock-free combiner and the seam entry points on the GPU box -- tests, the concurrent-submitter
 # bench at 1 ... 256 threads (3 runs each), the ThreadSanitizer / AddressSanitizer builds (tools/asan_host_check.sh build ... first, here).
 cd $GRAFT_REPO_ROOT; TAG=${1:-r06_c}; O=gpurun_out/$TAG; mkdir -p $O
 python -c "import __graft_entry__ as g; g.build()" > $O/build.txt 2>&1
