@@ -502,7 +502,7 @@ class Context:
 
     OPTIONS = {"quad_max": 1, "oct_max": 2, "ks_mfma_min": 3, "frozen": 4, "combine_max": 5, "combine_launches": 6,
                "combine_requests": 7, "ks_wide_ct": 8, "clone_path": 9, "clone_force_host": 10,
-               "combine_us_idle": 11, "combine_us_gather": 12, "combine_us_launch": 13}
+               "combine_us_idle": 11, "combine_us_gather": 12, "combine_us_launch": 13, "combine_quiet_us": 14}
     CLONE_PATHS = {0: "not a clone", 1: "same device (D2D)", 2: "peer copy (xGMI)", 3: "host-staged (no peer access)"}
 
     def set_option(self, name, value):

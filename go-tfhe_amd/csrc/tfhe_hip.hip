@@ -88,6 +88,8 @@ struct DevBuf {
 
 } // namespace
 
+constexpr int kCombQuietUsDefault = 150;
+
 struct tfhe_ctx {
     tfhe_params P{};
     int device = 0;
@@ -174,6 +176,8 @@ struct tfhe_ctx {
     // idle = previous launch done -> this one issued; gather = the part of it the leader spent waiting for returning callers;
     // launch = transfers + kernels + synchronisation
     std::atomic<long long> comb_ns_idle{0}, comb_ns_gather{0}, comb_ns_launch{0};
+    std::atomic<long long> comb_exit[6];     // how the gathering waits ended (TFHE_OPT_COMBINE_EXIT_*): nobody to wait for, stale, all back, batch full, quiet window, deadline
+    std::atomic<int> comb_quiet_us{kCombQuietUsDefault};     // TFHE_OPT_COMBINE_QUIET_US: how long the gathering leader waits without a new arrival before it launches
     std::vector<uint32_t> gate_tv_host;                 // the gate test vector (a combined bootstrap launch carries one table per item)
     void *hdr_host[2] = {nullptr, nullptr};             // page-locked key-blob headers (tfhe_key_export_dev): the asynchronous copy
                                                         // reads them after the call has returned
@@ -870,7 +874,7 @@ int bootstrap_batch_serial(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, 
 int combine_cap(const tfhe_ctx *c, int kind)
 {
     (void)kind;
-    if (c->shape == kShapeN1024_L3_B6) return 2 * launch_items(c);       // rows are bounded by the staging (launch_items); a MUX row is two bootstraps
+    if (c->shape == kShapeN1024_L3_B6) return 2 * c->num_cus;            // rows are bounded by the staging (one per CU); a MUX row is two bootstraps
     int cap = c->num_cus;
     if (shape_is_1024(c->shape)) {              // the small-launch kernels exist at the N = 1024 shapes only
         const int q = c->quad_limit.load(), o = c->oct_limit.load();
@@ -889,10 +893,14 @@ int combine_weight(const tfhe_ctx::GateReq &r)
     return may_mux ? 2 * r.B : r.B;
 }
 
+// Rows of one combined launch = rows of its page-locked staging: one per CU.  That is the scalar-caller case combining exists for (a
+// launch of 1 ... one bootstrap per CU costs the same ~2.2 ms); larger staging only bought the merging of mid-size batches and cost
+// 9 ms of hipHostMalloc at the first contention -- inside which the other callers went one by one (round 6 trace: 34 MB for 1,024 rows;
+// 8.6 MB for 256 rows is 2.3 ms).  Requests of more rows take the serial path.
 int combine_rows(const tfhe_ctx *c, int kind)
 {
-    const int cap = combine_cap(c, kind), li = launch_items(c);
-    return cap < li ? cap : li;
+    const int cap = combine_cap(c, kind);
+    return cap < c->num_cus ? cap : c->num_cus;
 }
 
 long long steady_ns()
@@ -1096,10 +1104,13 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
     // without them makes two cohorts that take turns (each launch half as full as it could be at the same cost)
     long long ns_gather = 0;
     const long long prev_done_ns = Q.last_done_ns.load(std::memory_order_relaxed);
-    if (Q.returning.load(std::memory_order_acquire) > 0) {
+    if (Q.returning.load(std::memory_order_acquire) <= 0) {
+        c->comb_exit[0]++;
+    } else {
         const long long t_in = steady_ns();
         if (t_in - prev_done_ns > 1000000) {
             Q.returning.store(0, std::memory_order_relaxed);                                     // stale: those callers went elsewhere long ago
+            c->comb_exit[1]++;
         } else {
             // the first kGatherSpinNs busy-polling (the GPU is idle and every caller of the context is waiting for this launch: a sleeping
             // leader adds a second thread wake-up -- 50-100 us out of an idle core -- to every round), then asleep on the futex word
@@ -1110,13 +1121,19 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
                 for (int i = 0; i < 32; i++) __builtin_ia32_pause();
                 done = gathered();
             }
+            int why = 0;
             while (!done) {
                 const uint32_t g = Q.gather.load(std::memory_order_acquire);
                 const uint64_t seen = bt.claim.load(std::memory_order_acquire);
                 if (gathered()) break;
-                futex_wait(Q.gather, g, 150);
-                if (bt.claim.load(std::memory_order_acquire) == seen || steady_ns() - t_in > 600000) break;      // quiet for 150 us, or 600 us in all
+                const long quiet_us = c->comb_quiet_us.load(std::memory_order_relaxed);
+                futex_wait(Q.gather, g, quiet_us);
+                if (gathered()) break;
+                if (bt.claim.load(std::memory_order_acquire) == seen) { why = 4; break; }             // quiet for one window
+                if (steady_ns() - t_in > 4000LL * quiet_us) { why = 5; break; }                      // four windows in all
             }
+            if (!why) why = bt.full.load(std::memory_order_acquire) ? 3 : 2;
+            c->comb_exit[why]++;
             Q.returning.store(0, std::memory_order_relaxed);
             ns_gather = steady_ns() - t_in;
         }
@@ -1177,6 +1194,10 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
             }
         }
     }
+#ifdef TFHE_COMBINE_TRACE
+    std::fprintf(stderr, "[combine] t=%lld us batch=%d rows=%d followers=%d gather_us=%lld tid=%ld\n", steady_ns() / 1000 % 100000000, bi, rows, nfollow,
+                 ns_gather / 1000, (long)syscall(SYS_gettid));
+#endif
     // settle: followers may read their request and their rows from here on
     bt.readers.store(nfollow, std::memory_order_relaxed);
     Q.last_done_ns.store(steady_ns(), std::memory_order_relaxed);
@@ -1266,7 +1287,8 @@ int tfhe_ctx_create(const tfhe_params *P, int device_id, tfhe_ctx **out)
     c->quad_limit = c->num_cus;
     c->oct_limit = c->num_cus;
     c->ks_mfma_min = kKsMfmaMinDefault;
-    c->combine_max = launch_items(c);      // requests of up to one launch's worth of gates are combined (tfhe_gate_batch)
+    c->combine_max = c->num_cus;           // requests of up to one bootstrap per CU are combined (tfhe_gate_batch): the staging's rows
+    for (auto &e : c->comb_exit) e.store(0);
     for (int kind = 0; kind < 2; kind++) {  // the combining queues: batch 0 open, the other two idle (closed, done)
         c->comb[kind].cap_rows = combine_rows(c, kind);
         c->comb[kind].ring[0].done.store(0);
@@ -1360,7 +1382,8 @@ int tfhe_ctx_set_option(tfhe_ctx *c, int option, int value)
         }
         return TFHE_OK;
     case TFHE_OPT_FROZEN: c->frozen = value != 0; return TFHE_OK;
-    case TFHE_OPT_COMBINE_MAX: c->combine_max = value < 0 ? launch_items(c) : value; return TFHE_OK;
+    case TFHE_OPT_COMBINE_MAX: c->combine_max = value < 0 ? c->num_cus : value; return TFHE_OK;
+    case TFHE_OPT_COMBINE_QUIET_US: c->comb_quiet_us = value < 0 ? kCombQuietUsDefault : value < 20 ? 20 : value > 5000 ? 5000 : value; return TFHE_OK;
     case TFHE_OPT_CLONE_FORCE_HOST: c->clone_force_host = value != 0; return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT:
         if (value > 0 && value != 64 && value != 128) return fail(TFHE_E_INVALID, "TFHE_OPT_KS_WIDE_CT is 64, 128 or 0 / -1 (by batch size)");
@@ -1380,6 +1403,7 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_KS_MFMA_MIN: *value = c->ks_mfma_min; return TFHE_OK;
     case TFHE_OPT_FROZEN: *value = c->frozen ? 1 : 0; return TFHE_OK;
     case TFHE_OPT_COMBINE_MAX: *value = c->combine_max.load(); return TFHE_OK;
+    case TFHE_OPT_COMBINE_QUIET_US: *value = c->comb_quiet_us.load(); return TFHE_OK;
     case TFHE_OPT_KS_WIDE_CT: *value = c->ks_wide_ct; return TFHE_OK;
     case TFHE_OPT_CLONE_PATH: *value = c->clone_path; return TFHE_OK;
     case TFHE_OPT_CLONE_FORCE_HOST: *value = c->clone_force_host ? 1 : 0; return TFHE_OK;
@@ -1389,6 +1413,9 @@ int tfhe_ctx_get_option(tfhe_ctx *c, int option, int *value)
     case TFHE_OPT_COMBINE_US_IDLE: *value = (int)std::min<long long>(c->comb_ns_idle.load() / 1000, INT_MAX); return TFHE_OK;
     case TFHE_OPT_COMBINE_US_GATHER: *value = (int)std::min<long long>(c->comb_ns_gather.load() / 1000, INT_MAX); return TFHE_OK;
     case TFHE_OPT_COMBINE_US_LAUNCH: *value = (int)std::min<long long>(c->comb_ns_launch.load() / 1000, INT_MAX); return TFHE_OK;
+    case TFHE_OPT_COMBINE_EXIT_NONE: case TFHE_OPT_COMBINE_EXIT_NONE + 1: case TFHE_OPT_COMBINE_EXIT_NONE + 2: case TFHE_OPT_COMBINE_EXIT_NONE + 3:
+    case TFHE_OPT_COMBINE_EXIT_NONE + 4: case TFHE_OPT_COMBINE_EXIT_NONE + 5:
+        *value = (int)std::min<long long>(c->comb_exit[option - TFHE_OPT_COMBINE_EXIT_NONE].load(), INT_MAX); return TFHE_OK;
     default: return fail(TFHE_E_INVALID, "unknown option %d", option);
     }
 }
@@ -1750,7 +1777,7 @@ int tfhe_ctx_clone_to(tfhe_ctx *src, int device_id, tfhe_ctx **out)
     } guard{dst};
     // the per-context limits travel with the key: a clone dispatches like its source
     dst->quad_limit = src->quad_limit.load(); dst->oct_limit = src->oct_limit.load(); dst->ks_mfma_min = src->ks_mfma_min;
-    dst->ks_wide_ct = src->ks_wide_ct; dst->combine_max = src->combine_max.load();
+    dst->ks_wide_ct = src->ks_wide_ct; dst->combine_max = src->combine_max.load(); dst->comb_quiet_us = src->comb_quiet_us.load();
     bool peers = false;
     void *bounce = nullptr;
     struct Bounce { void *&p; ~Bounce() { if (p) (void)hipHostFree(p); } } bounce_guard{bounce};

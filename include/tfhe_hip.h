@@ -120,13 +120,19 @@ enum {
     TFHE_OPT_FROZEN = 4,       /* 1 while a captured hipGraph may hold the intermediate buffers' addresses (set by the
                                   library, see tfhe_ctx_reserve); the caller clears it once those graphs are destroyed    */
     TFHE_OPT_COMBINE_MAX = 5,  /* tfhe_gate_batch calls of at most this many gates are COMBINED with concurrent callers'
-                                  (see tfhe_gate_batch); default (and -1) = one launch's worth, 0 = never                  */
+                                  (see tfhe_gate_batch); default (and -1) = one per CU (also the most a combined launch
+                                  carries: the rows of its page-locked staging), 0 = never                                  */
     TFHE_OPT_COMBINE_LAUNCHES = 6,  /* read-only: combined launches issued so far ...                                       */
     TFHE_OPT_COMBINE_REQUESTS = 7,  /* ... and the tfhe_gate_batch calls they carried                                       */
     TFHE_OPT_COMBINE_US_IDLE = 11,  /* read-only, microseconds summed over the combined launches of back-to-back rounds: from the previous
                                        launch's completion to this one's issue (the GPU-idle gap combining leaves between rounds) ...    */
     TFHE_OPT_COMBINE_US_GATHER = 12,/* ... the part of it the launch's leader spent waiting for the previous launch's callers to return ... */
     TFHE_OPT_COMBINE_US_LAUNCH = 13,/* ... and transfers + kernels + synchronisation of the combined launches themselves                   */
+    TFHE_OPT_COMBINE_QUIET_US = 14, /* how long (microseconds, 20 ... 5000) the leader of a combined launch waits WITHOUT a new arrival for the callers of
+                                       the previous launch before it goes without them (four such windows at most); -1 = default                    */
+    TFHE_OPT_COMBINE_EXIT_NONE = 15, /* read-only, 15 ... 20: how the leaders' gathering waits ended, counted per launch they led: nobody to wait for (15),
+                                        the previous launch was long ago (16), every caller back (17), batch full (18), a quiet window passed (19),
+                                        four windows in all (20)                                                                               */
     TFHE_OPT_KS_WIDE_CT = 8,   /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
                                   only: one wave per SIMD, slower)                                                         */
     TFHE_OPT_CLONE_FORCE_HOST = 10, /* tests: 1 = clones OF this context take the host-staged path (the fallback of devices that are
@@ -294,14 +300,17 @@ int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, 
  * tfhe_ctx_sync).
  *
  * Concurrent callers of the host-pointer variant (any number of threads on ONE context) are COMBINED, not serialised: a
- * launch of 1 ... 256 bootstraps costs the same ~2.3 ms, so while one caller's launch is in flight the others queue, and the
- * next launch carries ALL queued requests as one gate batch with per-item op codes; each caller gets exactly its rows back --
- * bit-identical to what a call on its own returns (a gate's result depends on its own operands only).  There is no extra
- * thread and a lone caller is launched at once, exactly as before; only a caller that takes the lead right behind a combined
- * launch waits (bounded, <= ~0.2 ms) for the callers that launch carried to come back.  Calls of more than TFHE_OPT_COMBINE_MAX gates
- * take the context for themselves.  (The reference's scalar gates.* share one evaluator that is not goroutine-safe,
- * gates.go:19-23; its concurrency is one pooled evaluator per goroutine, trgsw.go:227-252 -- this is what replaces it.)
- * If a combined launch fails, every call it carried returns that error. */
+ * launch of 1 ... one bootstrap per CU costs the same ~2.2 ms, so while one launch is in flight the other callers claim rows of the
+ * next batch's page-locked staging (lock-free; each copies its own operands in) and the next launch carries ALL of them as one gate
+ * batch with per-item op codes; each caller takes exactly its rows out -- bit-identical to what a call on its own returns (a gate's
+ * result depends on its own operands only; at the parameter shapes whose transforms are not exact a combined launch stays within
+ * the kernel shape a lone small call runs, a MUX row counting as two bootstraps).  There is no extra thread and a lone caller is
+ * launched at once; the caller that leads a batch right behind a combined launch waits for that launch's callers to come back
+ * (ends when all are back, after TFHE_OPT_COMBINE_QUIET_US without a new arrival, or after four such windows).  A combined launch
+ * carries at most one row per CU; calls of more than TFHE_OPT_COMBINE_MAX gates (default: the same) take the context for themselves.
+ * (The reference's scalar gates.* share one evaluator that is not goroutine-safe, gates.go:19-23; its concurrency is one pooled
+ * evaluator per goroutine, trgsw.go:227-252 -- this is what replaces it.)  If a combined launch fails for a reason only the
+ * combination has, its calls are re-issued one by one, each with its own result. */
 int tfhe_gate_batch(tfhe_ctx *ctx, const uint8_t *ops, int op_uniform, const uint32_t *a,
                     const uint32_t *b, const uint32_t *c, uint32_t *out, int B);
 int tfhe_gate_batch_dev(tfhe_ctx *ctx, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a,

@@ -76,6 +76,7 @@ int main(int argc, char **argv)
     for (auto &v : s0) v = gen() & 1;
     for (auto &v : s1) v = gen() & 1;
     CK(tfhe_keygen_cloud(ctx, s0.data(), s1.data(), 2.0e-5, 2.0e-8, 11));
+    if (argc > 3) CK(tfhe_ctx_set_option(ctx, TFHE_OPT_COMBINE_QUIET_US, std::atoi(argv[3])));      // combine_bench T quick <quiet_us>
     const int n1 = P.n + 1;
     std::vector<std::vector<uint32_t>> in(T, std::vector<uint32_t>((size_t)16 * n1));
     for (auto &v : in) for (auto &w : v) w = (uint32_t)gen();
@@ -112,6 +113,8 @@ int main(int argc, char **argv)
     CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_US_IDLE, &us_idle));
     CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_US_GATHER, &us_gather));
     CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_US_LAUNCH, &us_launch));
+    int ex[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 6; i++) CK(tfhe_ctx_get_option(ctx, TFHE_OPT_COMBINE_EXIT_NONE + i, &ex[i]));
     const int nl = l1 - l0 > 0 ? l1 - l0 : 1;
     const bool quick = argc > 2 && std::string(argv[2]) == "quick";      // skip the serialised comparison (0.7 s)
     CK(tfhe_ctx_set_option(ctx, TFHE_OPT_COMBINE_MAX, 0));
@@ -119,8 +122,10 @@ int main(int argc, char **argv)
     const double serial = quick ? 0.0 : run(Ts);
     std::printf("{\"threads\": %d, \"gate_calls\": %d, \"ms\": %.1f, \"combined_launches\": %d, \"calls_carried\": %d, "
                 "\"per_combined_launch_us\": {\"idle_before\": %.0f, \"of_which_gathering\": %.0f, \"launch\": %.0f}, "
+                "\"gather_exits\": {\"none\": %d, \"stale\": %d, \"all_back\": %d, \"full\": %d, \"quiet\": %d, \"deadline\": %d}, "
                 "\"one_thread_40_gates_ms\": %.1f, \"serialised_%d_threads_ms\": %.1f, \"serialised_all_threads_projected_ms\": %.0f}\n",
-                T, 40 * T, ms, l1 - l0, r1 - r0, (double)us_idle / nl, (double)us_gather / nl, (double)us_launch / nl, one, Ts, serial, serial / Ts * T);
+                T, 40 * T, ms, l1 - l0, r1 - r0, (double)us_idle / nl, (double)us_gather / nl, (double)us_launch / nl,
+                ex[0], ex[1], ex[2], ex[3], ex[4], ex[5], one, Ts, serial, serial / Ts * T);
     CK(tfhe_ctx_destroy(ctx));
     std::fflush(stdout);
     return 0;
