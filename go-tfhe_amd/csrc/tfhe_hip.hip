@@ -4,6 +4,7 @@
 // There is NO CPU fallback: every entry point either runs the gfx950 kernels or fails with a
 // TFHE_E_* code.
 #include "../../include/tfhe_hip.h"
+#include "tfhe_hip_internal.hpp"
 
 #include <hip/hip_runtime.h>
 #include <linux/futex.h>

@@ -130,13 +130,8 @@ enum {
     TFHE_OPT_COMBINE_US_LAUNCH = 13,/* ... and transfers + kernels + synchronisation of the combined launches themselves                   */
     TFHE_OPT_COMBINE_QUIET_US = 14, /* how long (microseconds, 20 ... 5000) the leader of a combined launch waits WITHOUT a new arrival for the callers of
                                        the previous launch before it goes without them (four such windows at most); -1 = default                    */
-    TFHE_OPT_COMBINE_EXIT_NONE = 15, /* read-only, 15 ... 20: how the leaders' gathering waits ended, counted per launch they led: nobody to wait for (15),
-                                        the previous launch was long ago (16), every caller back (17), batch full (18), a quiet window passed (19),
-                                        four windows in all (20)                                                                               */
     TFHE_OPT_KS_WIDE_CT = 8,   /* wide key switch (bases 16-64): ciphertexts per wave, 64 (default: 0, -1) or 128 (measurements
                                   only: one wave per SIMD, slower)                                                         */
-    TFHE_OPT_CLONE_FORCE_HOST = 10, /* tests: 1 = clones OF this context take the host-staged path (the fallback of devices that are
-                                  not peers) whatever the devices are, so that the path is exercised on a one-GPU box          */
     TFHE_OPT_CLONE_PATH = 9    /* read-only: how tfhe_ctx_clone_to brought this context's keys here: 0 = not a clone, 1 = same
                                   GPU (device-to-device copy), 2 = peer copy GPU to GPU (xGMI), 3 = staged through page-locked
                                   host memory (the devices are not peers)                                                  */

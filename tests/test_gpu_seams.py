@@ -96,7 +96,7 @@ def test_sample_extract_any_index(pkg, oracle, keys_small, ck_small):
             ck_small.ctx.sample_extract_batch(trl, bad)
 
 
-@pytest.mark.parametrize("B", [1, 7, 40, 300])
+@pytest.mark.parametrize("B", [1, 7, 40, 300, 1100, 2100])            # 1100, 2100: across the matrix-core key switch's 1,024-ciphertext chunks
 def test_keyswitch_on_extracted_samples_equals_the_fused_form_and_the_oracle(oracle, keys_small, ck_small, B):
     k = keys_small
     rs = np.random.RandomState(35 + B)

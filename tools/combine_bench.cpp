@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../include/tfhe_hip.h"
+#include "../go-tfhe_amd/csrc/tfhe_hip_internal.hpp"      // the gather-exit counters (measurement-only option ids)
 
 #define CK(x) do { int rc_ = (x); if (rc_) { std::printf("FAILED %s: %s\n", #x, tfhe_last_error()); std::exit(1); } } while (0)
 
