@@ -80,6 +80,15 @@ def run_world(world, timeout=600):
     return json.loads(lines[-1])
 
 
+def test_the_multirank_worker_itself_runs_over_rccl_with_one_rank(built):
+    # the worker the multi-device tests launch, executed where only one device exists: one RCCL rank goes through the key broadcast,
+    # the packed scatter / gather, the circuits sharded by circuit and the per-rank oracle comparison -- so that the first box with
+    # two devices tests the fan-out, not the script
+    rec = run_world(1)
+    assert rec["world_size"] == 1 and rec["collective_backend"] == "nccl" and rec["ranks_verified"] == 1 and rec["verified"]
+    assert all(rec["root_checks"].values()), rec["root_checks"]
+
+
 @needs2
 @pytest.mark.parametrize("world", sorted({2, min(NDEV, 8)} if NDEV >= 2 else {2}))
 def test_rccl_sharded_gates_and_circuits_with_several_ranks(built, world):
