@@ -313,18 +313,23 @@ def test_shim_calls_every_entry_point_with_the_declared_argument_count():
         assert 'import "C"' not in _read(other), f"{other} must not touch cgo: package gpu is the only cgo layer"
 
 
-def test_recorded_run_of_the_shims_own_go_test():
-    """shim/go/gates/gates_gpu_test.go -- what a Go user of the shim runs -- executed offline by the interpreter (cgo's C mocked on the oracle):
-    no failure in its three Test functions (every gate word for word against the reference's own), 60 gates through the C ABI, every context
-    the tests created released by their deferred gates.Release."""
+def test_recorded_run_of_the_shims_own_go_tests():
+    """shim/go/gates/gates_gpu_test.go and shim/go/trgsw/trgsw_gpu_test.go -- what a Go user of the shim runs -- executed offline by the interpreter
+    (cgo's C mocked on the oracle): no failure in their five Test functions (every gate, and every seam function of trgsw / trlwe, word for word
+    against the reference's own), 60 gates through the C ABI, every key context the tests created released by their deferred Release / Detach calls
+    (what stays alive is the one key-less scratch context of the seam calls, by design)."""
     import json
     path = os.path.join(ROOT, "tests", "golden", "goref", "shim_go_test_run.json")
     if not os.path.exists(path):
         pytest.skip("tests/golden/goref/shim_go_test_run.json not generated (make_goref_vectors.py --jobs shim_go_test)")
     rec = json.load(open(path))
     assert "NOT the Go toolchain" in rec["what"]
-    assert sorted(rec["tests"]) == ["TestBatchGates", "TestMUXNotCopyConstant", "TestScalarGatesTruthTablesAndWordParity"]
+    assert sorted(rec["tests"]) == ["TestBatchGates", "TestBlindRotateExtractAndKeySwitchEqualTheReferences", "TestExternalProductAndCMUXWithAFreeStandingOperand",
+                                    "TestMUXNotCopyConstant", "TestScalarGatesTruthTablesAndWordParity"]
     for name, t in rec["tests"].items():
         assert t["failures"] == [] and not t["skipped"] and t["statements"] > 10**6, (name, t)
-    assert rec["c_abi_calls"]["gate_batch"] == 60 and rec["c_abi_calls"]["load_bsk"] == 3
-    assert rec["contexts_created"] == 6 and rec["contexts_alive_at_end"] == 0           # per test: one upload (serves device 0) + one clone
+    c = rec["c_abi_calls"]
+    assert c["gate_batch"] == 60 and c["load_bsk"] == 4 and c["external_product_with"] == 1 and c["cmux_with"] == 1
+    assert c["blind_rotate_batch"] == 3 and c["sample_extract_batch"] == 4 and c["keyswitch_batch"] == 2       # batch of 3 over two devices + one scalar
+    assert rec["contexts_created_by_the_gate_tests"] == 6           # per gate test: one upload (serves device 0) + one clone
+    assert rec["contexts_alive_at_end"] == 1                        # gpu.Scratch()

@@ -560,10 +560,15 @@ def job_shim_go_test(_):
     pkg = I.pkg_by_import(f"{MOD}/gates")
     t0 = time.time()
     res = I.run_reference_tests("gates", pkg=pkg, directory=os.path.join(ROOT, "shim", "go", "gates"))
+    n_gate_ctx = len(mock.ctxs)
+    # ... and the seam packages' test (shim/go/trgsw/trgsw_gpu_test.go: trgsw.* and trlwe.SampleExtractIndex against the reference's own)
+    tpkg = I.pkg_by_import(f"{MOD}/trgsw")
+    res.update(I.run_reference_tests("trgsw", pkg=tpkg, directory=os.path.join(ROOT, "shim", "go", "trgsw")))
     calls = [c[0] for c in mock.calls]
     out = {"what": "shim/go/gates/gates_gpu_test.go executed by tools/go_static/gointerp.py (NOT the Go toolchain) with cgo's C mocked on the CPU oracle, "
                    "LWE dimension 1", "seconds": round(time.time() - t0), "tests": res, "c_abi_calls": {k: calls.count(k) for k in sorted(set(calls))},
-           "contexts_created": len(mock.ctxs), "contexts_alive_at_end": sum(c is not None for c in mock.ctxs)}   # `defer gates.Release(ck)` ran
+           "contexts_created": len(mock.ctxs), "contexts_created_by_the_gate_tests": n_gate_ctx,
+           "contexts_alive_at_end": sum(c is not None for c in mock.ctxs)}   # `defer gates.Release(ck)` ran; the seam test keeps the key-less scratch context
     for k, v in res.items():
         print(f"[goref] {k}: failures {v['failures']} ({v['statements']} statements)", flush=True)
     with open(os.path.join(OUT, "shim_go_test_run.json"), "w") as fh:
