@@ -171,6 +171,16 @@ struct tfhe_ctx {
         int cap_rows = 0;
     };
     CombQueue comb[2];
+    // Host-pointer gate batches of more than one row per CU (up to one pipelined piece) from SEVERAL callers overlap: two slots of device
+    // operand / result buffers, the upload of one call on the transfer stream while the kernels of the previous one run (gate_batch_overlapped)
+    struct HostSlot {
+        std::mutex mu;                  // held for a whole call: the slot's buffers are that call's
+        DevBuf in0, in1, in2, out, ops;
+        hipEvent_t up = nullptr, done = nullptr;
+    };
+    HostSlot hslot[2];
+    std::atomic<unsigned> hticket{0};
+    std::mutex up_mu, down_mu;          // one uploader, one downloader at a time (PCIe is one pipe each way); kernels under `mu`
     std::atomic<int> combine_max{0};        // requests of at most this many items are combined (TFHE_OPT_COMBINE_MAX; 0 = off)
     std::atomic<long long> comb_launches{0}, comb_requests{0};     // combined launches issued / requests they carried (TFHE_OPT_COMBINE_*)
     // where the time between two combined launches goes (TFHE_OPT_COMBINE_US_*; nanoseconds, summed over the combined launches):
@@ -824,12 +834,69 @@ int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const 
     return TFHE_OK;
 }
 
+// Host-pointer gate batches of 257 ... pipe_items gates (what a Go service submits from several goroutines: gates.Batch* on host memory):
+// the three phases of a call -- operands up, kernels, results down -- hold three different locks, and a call works in one of two buffer
+// slots, so the upload of caller B runs on the transfer stream while caller A's kernels run, and A's results go down while B computes.
+// A lone caller goes through the same three phases back to back (two event waits more than the serial path).  The kernels themselves
+// still run one call at a time under the context mutex (they share the scratch), so results are exactly the serial path's.
+int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b, const uint32_t *cc,
+                          uint32_t *out, int B)
+{
+    int rc;
+    HIP_TRY(hipSetDevice(c->device));
+    tfhe_ctx::HostSlot &S = c->hslot[c->hticket.fetch_add(1, std::memory_order_relaxed) & 1];
+    std::lock_guard<std::mutex> slot(S.mu);
+    const size_t rows = (size_t)B * (c->P.n + 1) * 4;
+    {
+        std::lock_guard<std::mutex> up(c->up_mu);
+        if (!c->h2d_stream) {
+            std::lock_guard<std::recursive_mutex> lk(c->mu);          // the pipelined path creates the same streams under this mutex
+            if (!c->h2d_stream) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+                HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+                for (auto &pr : c->pipe_ev)
+                    for (auto &e : pr) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
+        }
+        if (!S.up) {
+            HIP_TRY(hipEventCreateWithFlags(&S.up, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        }
+        if ((rc = S.in0.reserve(rows)) || (rc = S.in1.reserve(rows)) || (rc = S.out.reserve(rows))) return rc;
+        if (cc && (rc = S.in2.reserve(rows))) return rc;
+        if (ops && (rc = S.ops.reserve((size_t)B))) return rc;
+        HIP_TRY(hipMemcpyAsync(S.in0.p, a, rows, hipMemcpyHostToDevice, c->h2d_stream));
+        HIP_TRY(hipMemcpyAsync(S.in1.p, b, rows, hipMemcpyHostToDevice, c->h2d_stream));
+        if (cc) HIP_TRY(hipMemcpyAsync(S.in2.p, cc, rows, hipMemcpyHostToDevice, c->h2d_stream));
+        if (ops) HIP_TRY(hipMemcpyAsync(S.ops.p, ops, (size_t)B, hipMemcpyHostToDevice, c->h2d_stream));
+        HIP_TRY(hipEventRecord(S.up, c->h2d_stream));
+    }
+    {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        HIP_TRY(hipStreamWaitEvent(c->stream, S.up, 0));
+        if ((rc = gate_batch_device(c, ops ? S.ops.as<uint8_t>() : nullptr, op_uniform, S.in0.as<uint32_t>(), S.in1.as<uint32_t>(),
+                                    cc ? S.in2.as<uint32_t>() : nullptr, S.out.as<uint32_t>(), B, c->stream))) {
+            (void)hipStreamSynchronize(c->stream);                    // nothing of this call may still read the slot when it is released
+            return rc;
+        }
+        HIP_TRY(hipEventRecord(S.done, c->stream));
+    }
+    {
+        std::lock_guard<std::mutex> down(c->down_mu);
+        HIP_TRY(hipStreamWaitEvent(c->d2h_stream, S.done, 0));
+        HIP_TRY(hipMemcpyAsync(out, S.out.p, rows, hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+    }
+    return TFHE_OK;
+}
+
 // The host-pointer gate batch of ONE caller: stage, launch, read back, under the context mutex.
 int gate_batch_serial(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b, const uint32_t *cc,
                       uint32_t *out, int B)
 {
     int rc;
     HIP_TRY(hipSetDevice(c->device));        // here, not in tfhe_gate_batch: a caller that only FOLLOWS a combined launch never touches the HIP runtime
+    if (B > c->num_cus && B <= pipe_items(c)) return gate_batch_overlapped(c, ops, op_uniform, a, b, cc, out, B);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (B > pipe_items(c)) return gate_batch_pipelined(c, ops, op_uniform, a, b, cc, out, B);
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
@@ -1337,6 +1404,10 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto &Q : c->comb)
         for (auto &b : Q.ring) if (b.host) (void)hipHostFree(b.host);
+    for (auto &S : c->hslot) {
+        for (DevBuf *b : {&S.in0, &S.in1, &S.in2, &S.out, &S.ops}) b->release();
+        for (hipEvent_t e : {S.up, S.done}) if (e) (void)hipEventDestroy(e);
+    }
     for (void *h : c->hdr_host) if (h) (void)hipHostFree(h);
     for (auto &pr : c->pipe_ev)
         for (auto &e : pr) if (e) (void)hipEventDestroy(e);

@@ -332,3 +332,47 @@ def test_combined_gates_at_a_tolerance_regime_shape_equal_lone_calls(oracle, pkg
         assert ctx.get_option("combine_requests") > before
     finally:
         ck.close()
+
+
+def test_mid_size_host_batches_from_several_threads_overlap_and_equal_lone_calls(oracle, keys_small, ck_small, pkg):
+    # gates.Batch* on host memory from several goroutines: batches of more than one row per CU are not combined, their uploads / kernels /
+    # downloads overlap across callers in two buffer slots (gate_batch_overlapped).  Every result must equal the same call issued alone --
+    # and the oracle -- whatever ran beside it: uniform ops, per-item ops with MUX, ragged sizes around the CU count and the launch size.
+    import torch
+    k, ctx = keys_small, ck_small.ctx
+    n1 = k.p.n + 1
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rs = np.random.RandomState(123)
+    rnd = lambda B: rs.randint(0, 2**32, size=(B, n1), dtype=np.uint64).astype(np.uint32)
+    T, CALLS = 5, 4
+    plan = []
+    for t in range(T):
+        calls = []
+        for i in range(CALLS):
+            B = int(rs.choice([cus + 1, 300, 777, 1024, 1025, 2100]))
+            ops = "XNOR" if (t + i) % 3 == 0 else rs.randint(0, 11, size=B).astype(np.uint8)
+            calls.append((ops, rnd(B), rnd(B), rnd(B)))
+        plan.append(calls)
+    want = [[ctx.gate_batch(ops, a, b, c if not isinstance(ops, str) else None) for ops, a, b, c in calls] for calls in plan]
+    got = [[None] * CALLS for _ in range(T)]
+    errors = []
+
+    def run(t):
+        try:
+            for i, (ops, a, b, c) in enumerate(plan[t]):
+                got[t][i] = ctx.gate_batch(ops, a, b, c if not isinstance(ops, str) else None)
+        except Exception as e:                          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in ts) and not errors, errors
+    for t in range(T):
+        for i in range(CALLS):
+            assert np.array_equal(got[t][i], want[t][i]), (t, i)
+    ops, a, b, c = plan[0][1]
+    ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops, a[:40], b[:40], c[:40] if not isinstance(ops, str) else None)
+    assert np.array_equal(got[0][1][:40], ref)

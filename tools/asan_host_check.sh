@@ -66,6 +66,7 @@ else
     run $D/combine_bench 64
     run $D/combine_bench 256
     run $D/combine_bench 64 pbs
+    run $D/combine_bench 4 batch 700 3          # mid-size host batches from several threads: the overlapped upload / kernels / download path
     [ -n "$FAILED" ] && exit 1
     echo "host code under ${SAN} sanitizer: no report"
 fi
