@@ -175,7 +175,7 @@ struct tfhe_ctx {
     // operand / result buffers, the upload of one call on the transfer stream while the kernels of the previous one run (gate_batch_overlapped)
     struct HostSlot {
         std::mutex mu;                  // held for a whole call: the slot's buffers are that call's
-        DevBuf in0, in1, in2, out, ops;
+        DevBuf in0, in1, in2, out, ops, tv;
         hipEvent_t up = nullptr, done = nullptr;
     };
     HostSlot hslot[2];
@@ -839,6 +839,25 @@ int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const 
 // slots, so the upload of caller B runs on the transfer stream while caller A's kernels run, and A's results go down while B computes.
 // A lone caller goes through the same three phases back to back (two event waits more than the serial path).  The kernels themselves
 // still run one call at a time under the context mutex (they share the scratch), so results are exactly the serial path's.
+// (called with up_mu held) the transfer streams and the slot's two events, made on first use
+int overlap_prepare(tfhe_ctx *c, tfhe_ctx::HostSlot &S)
+{
+    if (!c->h2d_stream) {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);          // the pipelined path creates the same streams under this mutex
+        if (!c->h2d_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
+            for (auto &pr : c->pipe_ev)
+                for (auto &e : pr) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+    }
+    if (!S.up) {
+        HIP_TRY(hipEventCreateWithFlags(&S.up, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    }
+    return TFHE_OK;
+}
+
 int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const uint32_t *a, const uint32_t *b, const uint32_t *cc,
                           uint32_t *out, int B)
 {
@@ -849,19 +868,7 @@ int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
     {
         std::lock_guard<std::mutex> up(c->up_mu);
-        if (!c->h2d_stream) {
-            std::lock_guard<std::recursive_mutex> lk(c->mu);          // the pipelined path creates the same streams under this mutex
-            if (!c->h2d_stream) {
-                HIP_TRY(hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
-                HIP_TRY(hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
-                for (auto &pr : c->pipe_ev)
-                    for (auto &e : pr) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            }
-        }
-        if (!S.up) {
-            HIP_TRY(hipEventCreateWithFlags(&S.up, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
-        }
+        if ((rc = overlap_prepare(c, S))) return rc;
         if ((rc = S.in0.reserve(rows)) || (rc = S.in1.reserve(rows)) || (rc = S.out.reserve(rows))) return rc;
         if (cc && (rc = S.in2.reserve(rows))) return rc;
         if (ops && (rc = S.ops.reserve((size_t)B))) return rc;
@@ -877,6 +884,41 @@ int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const
         if ((rc = gate_batch_device(c, ops ? S.ops.as<uint8_t>() : nullptr, op_uniform, S.in0.as<uint32_t>(), S.in1.as<uint32_t>(),
                                     cc ? S.in2.as<uint32_t>() : nullptr, S.out.as<uint32_t>(), B, c->stream))) {
             (void)hipStreamSynchronize(c->stream);                    // nothing of this call may still read the slot when it is released
+            return rc;
+        }
+        HIP_TRY(hipEventRecord(S.done, c->stream));
+    }
+    {
+        std::lock_guard<std::mutex> down(c->down_mu);
+        HIP_TRY(hipStreamWaitEvent(c->d2h_stream, S.done, 0));
+        HIP_TRY(hipMemcpyAsync(out, S.out.p, rows, hipMemcpyDeviceToHost, c->d2h_stream));
+        HIP_TRY(hipStreamSynchronize(c->d2h_stream));
+    }
+    return TFHE_OK;
+}
+
+// The same for programmable bootstraps (evaluator.BootstrapLUT over host batches, one table or one per item).
+int bootstrap_batch_overlapped(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, int tv_per_item, uint32_t *out, int B)
+{
+    int rc;
+    HIP_TRY(hipSetDevice(c->device));
+    tfhe_ctx::HostSlot &S = c->hslot[c->hticket.fetch_add(1, std::memory_order_relaxed) & 1];
+    std::lock_guard<std::mutex> slot(S.mu);
+    const size_t rows = (size_t)B * (c->P.n + 1) * 4;
+    const size_t tvb = tv ? (tv_per_item ? (size_t)B : 1) * 2 * c->P.N * 4 : 0;
+    {
+        std::lock_guard<std::mutex> up(c->up_mu);
+        if ((rc = overlap_prepare(c, S))) return rc;
+        if ((rc = S.in0.reserve(rows)) || (rc = S.out.reserve(rows)) || (tvb && (rc = S.tv.reserve(tvb)))) return rc;
+        HIP_TRY(hipMemcpyAsync(S.in0.p, in, rows, hipMemcpyHostToDevice, c->h2d_stream));
+        if (tv) HIP_TRY(hipMemcpyAsync(S.tv.p, tv, tvb, hipMemcpyHostToDevice, c->h2d_stream));
+        HIP_TRY(hipEventRecord(S.up, c->h2d_stream));
+    }
+    {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        HIP_TRY(hipStreamWaitEvent(c->stream, S.up, 0));
+        if ((rc = bootstrap_device(c, S.in0.as<uint32_t>(), tv ? S.tv.as<uint32_t>() : nullptr, tv_per_item, S.out.as<uint32_t>(), B, c->stream))) {
+            (void)hipStreamSynchronize(c->stream);
             return rc;
         }
         HIP_TRY(hipEventRecord(S.done, c->stream));
@@ -920,6 +962,7 @@ int bootstrap_batch_serial(tfhe_ctx *c, const uint32_t *in, const uint32_t *tv, 
 {
     int rc;
     HIP_TRY(hipSetDevice(c->device));
+    if (B > c->num_cus && B <= pipe_items(c)) return bootstrap_batch_overlapped(c, in, tv, tv_per_item, out, B);
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     const size_t inb = (size_t)B * (c->P.n + 1) * 4, trl = (size_t)B * 2 * c->P.N * 4;
     const size_t tvb = tv ? (tv_per_item ? trl : (size_t)2 * c->P.N * 4) : 0;
@@ -1405,7 +1448,7 @@ int tfhe_ctx_destroy(tfhe_ctx *c)
     for (auto &Q : c->comb)
         for (auto &b : Q.ring) if (b.host) (void)hipHostFree(b.host);
     for (auto &S : c->hslot) {
-        for (DevBuf *b : {&S.in0, &S.in1, &S.in2, &S.out, &S.ops}) b->release();
+        for (DevBuf *b : {&S.in0, &S.in1, &S.in2, &S.out, &S.ops, &S.tv}) b->release();
         for (hipEvent_t e : {S.up, S.done}) if (e) (void)hipEventDestroy(e);
     }
     for (void *h : c->hdr_host) if (h) (void)hipHostFree(h);

@@ -376,3 +376,48 @@ def test_mid_size_host_batches_from_several_threads_overlap_and_equal_lone_calls
     ops, a, b, c = plan[0][1]
     ref, _ = oracle.gate_batch(k.p, k.bsk, k.ksk, ops, a[:40], b[:40], c[:40] if not isinstance(ops, str) else None)
     assert np.array_equal(got[0][1][:40], ref)
+
+
+def test_mid_size_host_bootstrap_batches_from_several_threads_equal_lone_calls(oracle, keys_small, ck_small, pkg):
+    # evaluator.BootstrapLUT over host batches from several goroutines (one shared table, one table per item, or the gate test vector): batches of
+    # more than one sample per CU overlap across callers like the gate batches above (bootstrap_batch_overlapped); same words as lone calls and the oracle
+    import torch
+    k, ctx = keys_small, ck_small.ctx
+    n1, N = k.p.n + 1, k.p.N
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rs = np.random.RandomState(321)
+    w32 = lambda shape: rs.randint(0, 2**32, size=shape, dtype=np.uint64).astype(np.uint32)
+    T, CALLS = 4, 3
+    plan = []
+    for t in range(T):
+        calls = []
+        for i in range(CALLS):
+            B = int(rs.choice([cus + 1, 400, 1025]))
+            tv = [None, w32((2, N)), w32((B, 2, N))][(t + i) % 3]
+            calls.append((w32((B, n1)), tv))
+        plan.append(calls)
+    want = [[ctx.bootstrap_batch(cts, tv) for cts, tv in calls] for calls in plan]
+    got = [[None] * CALLS for _ in range(T)]
+    errors = []
+
+    def run(t):
+        try:
+            for i, (cts, tv) in enumerate(plan[t]):
+                got[t][i] = ctx.bootstrap_batch(cts, tv)
+        except Exception as e:                          # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for th in ts:
+        th.start()
+    for th in ts:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in ts) and not errors, errors
+    for t in range(T):
+        for i in range(CALLS):
+            assert np.array_equal(got[t][i], want[t][i]), (t, i)
+    cts, tv = plan[1][0]
+    tvi = k.tv if tv is None else tv
+    for i in (0, 7, len(cts) - 1):
+        table = tvi if tvi.ndim == 2 else tvi[i]
+        assert np.array_equal(got[1][0][i], oracle.bootstrap(k.p, k.bsk, k.ksk, cts[i], np.ascontiguousarray(table)))

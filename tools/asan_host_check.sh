@@ -67,6 +67,7 @@ else
     run $D/combine_bench 256
     run $D/combine_bench 64 pbs
     run $D/combine_bench 4 batch 700 3          # mid-size host batches from several threads: the overlapped upload / kernels / download path
+    run $D/combine_bench 3 batch 300 2 pbs      # ... and of programmable bootstraps
     [ -n "$FAILED" ] && exit 1
     echo "host code under ${SAN} sanitizer: no report"
 fi

@@ -65,24 +65,31 @@ static int pbs_mode(int T)
     return 0;
 }
 
-// `combine_bench.bin T batch B [K]`: T threads each issue K (default 6) host-pointer gate batches of B NAND gates from pageable memory on ONE
+// `combine_bench.bin T batch B [K] [pbs]`: T threads each issue K (default 6) host-pointer gate batches of B NAND gates from pageable memory on ONE
 // context -- what several goroutines calling gates.BatchNAND get.  Batches of 257 ... 16,384 gates overlap: one caller's upload and download run
 // while another's kernels do (gate_batch_overlapped in csrc/tfhe_hip.hip).
-static int batch_mode(int T, int B, int K)
+static int batch_mode(int T, int B, int K, bool pbs)
 {
     tfhe_params P{700, 1024, 10, 3, 6, 2, 9};
+    if (pbs) P = tfhe_params{1071, 2048, 11, 1, 22, 6, 3};          // Uint5: programmable bootstraps through one shared table
     tfhe_ctx *ctx = nullptr;
     CK(tfhe_ctx_create(&P, 0, &ctx));
     std::mt19937_64 gen(5);
     std::vector<uint32_t> s0(P.n), s1(P.N);
     for (auto &v : s0) v = gen() & 1;
     for (auto &v : s1) v = gen() & 1;
-    CK(tfhe_keygen_cloud(ctx, s0.data(), s1.data(), 2.0e-5, 2.0e-8, 11));
+    CK(tfhe_keygen_cloud(ctx, s0.data(), s1.data(), pbs ? 1.0e-7 : 2.0e-5, pbs ? 1.0e-15 : 2.0e-8, 11));
     const size_t n1 = P.n + 1;
+    std::vector<uint32_t> lut((size_t)2 * P.N);
+    for (auto &w : lut) w = (uint32_t)gen();
     std::vector<std::vector<uint32_t>> a(T, std::vector<uint32_t>((size_t)B * n1)), b(a), o(a);
     for (auto &v : a) for (auto &w : v) w = (uint32_t)gen();
     for (auto &v : b) for (auto &w : v) w = (uint32_t)gen();
-    auto work = [&](int t) { for (int k = 0; k < K; k++) CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_NAND, a[t].data(), b[t].data(), nullptr, o[t].data(), B)); };
+    auto call = [&](int t, uint32_t *dst) {
+        if (pbs) CK(tfhe_bootstrap_batch(ctx, a[t].data(), lut.data(), 0, dst, B));
+        else CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_NAND, a[t].data(), b[t].data(), nullptr, dst, B));
+    };
+    auto work = [&](int t) { for (int k = 0; k < K; k++) call(t, o[t].data()); };
     auto run = [&](int threads) {
         std::vector<std::thread> th;
         const auto t0 = std::chrono::steady_clock::now();
@@ -96,12 +103,12 @@ static int batch_mode(int T, int B, int K)
     std::vector<uint32_t> ref((size_t)B * n1);
     bool same = true;
     for (int t = 0; t < T; t++) {
-        CK(tfhe_gate_batch(ctx, nullptr, TFHE_OP_NAND, a[t].data(), b[t].data(), nullptr, ref.data(), B));
+        call(t, ref.data());
         same = same && ref == o[t];
     }
-    std::printf("{\"mode\": \"host batches\", \"threads\": %d, \"batch\": %d, \"calls_per_thread\": %d, \"one_thread_ms_per_call\": %.3f, \"one_thread_gates_per_s\": %.0f, "
+    std::printf("{\"mode\": \"host batches%s\", \"threads\": %d, \"batch\": %d, \"calls_per_thread\": %d, \"one_thread_ms_per_call\": %.3f, \"one_thread_gates_per_s\": %.0f, "
                 "\"all_threads_ms\": %.1f, \"all_threads_gates_per_s\": %.0f, \"outputs_equal_a_lone_call\": %s}\n",
-                T, B, K, one / K, 1e3 * B * K / one, ms, 1e3 * (double)B * K * T / ms, same ? "true" : "false");
+                pbs ? " (Uint5 PBS)" : "", T, B, K, one / K, 1e3 * B * K / one, ms, 1e3 * (double)B * K * T / ms, same ? "true" : "false");
     CK(tfhe_ctx_destroy(ctx));
     return same ? 0 : 1;
 }
@@ -110,7 +117,7 @@ int main(int argc, char **argv)
 {
     const int T = argc > 1 ? std::atoi(argv[1]) : 256;
     if (argc > 2 && std::string(argv[2]) == "pbs") return pbs_mode(T);
-    if (argc > 3 && std::string(argv[2]) == "batch") return batch_mode(T, std::atoi(argv[3]), argc > 4 ? std::atoi(argv[4]) : 6);
+    if (argc > 3 && std::string(argv[2]) == "batch") return batch_mode(T, std::atoi(argv[3]), argc > 4 ? std::atoi(argv[4]) : 6, argc > 5 && std::string(argv[5]) == "pbs");
     tfhe_params P{700, 1024, 10, 3, 6, 2, 9};                 // 128-bit set (params.go:151-180)
     tfhe_ctx *ctx = nullptr;
     CK(tfhe_ctx_create(&P, 0, &ctx));
