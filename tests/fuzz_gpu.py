@@ -125,6 +125,12 @@ def case_exact(rs, o, K, log):
         import threading
         T = int(rs.randint(2, 33))
         sizes = rs.randint(1, 9, T)
+        if rs.rand() < 0.3:                        # some callers with mid-size batches: not combined, overlapped across callers (gate_batch_overlapped)
+            T = min(T, 6)
+            sizes = sizes[:T]
+            for t in range(T):
+                if rs.rand() < 0.5:
+                    sizes[t] = int(rs.randint(cus + 1, cus + (60 if p.n > 40 else 400)))
         log.append(f"T={T}")
         jobs = []
         for t in range(T):
