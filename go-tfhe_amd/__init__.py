@@ -11,4 +11,4 @@ from .params import (Params, Security80Bit, Security110Bit, Security128Bit, Secu
 from ._binding import (Context, PinnedArray, TfheError, OPS, library_path, load_library, exported_symbols,  # noqa: F401
                        declared_symbols)
 from .cloudkey import CloudKey, CloudKeySet  # noqa: F401
-from . import gates, evaluator, lut  # noqa: F401
+from . import gates, evaluator, lut, trgsw, trlwe  # noqa: F401

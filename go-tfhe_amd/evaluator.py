@@ -14,9 +14,17 @@ class Evaluator:
         self.ctx = ck.ctx
         self.params = ck.params
 
-    # evaluator.go:50-81
-    def ExternalProductAssign(self, key_index, ct_in, ct_out):
-        ct_out[...] = self.ctx.external_product_batch(key_index, np.asarray(ct_in)[None])[0]
+    # evaluator.go:50-81.  ctFourierGGSW: an index into the resident bootstrapping key, or ANY TRGSW sample as the reference hands it over
+    # ([2L][2][N] float64 in its FourierPoly layout; then decompositionOffset, default the cloud key's, is a kernel operand)
+    def ExternalProductAssign(self, ctFourierGGSW, ct_in, ct_out, decompositionOffset=None):
+        if np.ndim(ctFourierGGSW) == 0:
+            ct_out[...] = self.ctx.external_product_batch(int(ctFourierGGSW), np.asarray(ct_in)[None])[0]
+        else:
+            ct_out[...] = self.ctx.external_product_with(ctFourierGGSW, np.asarray(ct_in)[None], decompositionOffset)[0]
+
+    # evaluator.go:85-106 : ctOut = ct0 + ctCond (x) (ct1 - ct0)
+    def CMuxAssign(self, ctCond, ct0, ct1, ct_out, decompositionOffset=None):
+        ct_out[...] = self.ctx.cmux_with(ctCond, np.asarray(ct0)[None], np.asarray(ct1)[None], decompositionOffset)[0]
 
     # evaluator.go:110-135 (nsteps < n stops the CMUX chain early: CMuxAssign seam, :85-106)
     def BlindRotateAssign(self, ct_in, testvec, ct_out, nsteps=-1):
