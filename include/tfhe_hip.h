@@ -305,7 +305,10 @@ int tfhe_extract_keyswitch_batch_dev(tfhe_ctx *ctx, const uint32_t *d_in_trlwe, 
  * carries at most one row per CU; calls of more than TFHE_OPT_COMBINE_MAX gates (default: the same) take the context for themselves.
  * (The reference's scalar gates.* share one evaluator that is not goroutine-safe, gates.go:19-23; its concurrency is one pooled
  * evaluator per goroutine, trgsw.go:227-252 -- this is what replaces it.)  If a combined launch fails for a reason only the
- * combination has, its calls are re-issued one by one, each with its own result. */
+ * combination has, its calls are re-issued one by one, each with its own result.
+ * Larger host-pointer calls (more than one gate per CU, up to 16 launches' worth) of several threads are not combined but OVERLAPPED:
+ * each works in one of two buffer slots, and one caller's upload / download runs while another's kernels do (the kernels themselves run
+ * one call at a time: same words as a lone call).  Longer calls pipeline their own transfers slab by slab. */
 int tfhe_gate_batch(tfhe_ctx *ctx, const uint8_t *ops, int op_uniform, const uint32_t *a,
                     const uint32_t *b, const uint32_t *c, uint32_t *out, int B);
 int tfhe_gate_batch_dev(tfhe_ctx *ctx, const uint8_t *d_ops, int op_uniform, const uint32_t *d_a,
