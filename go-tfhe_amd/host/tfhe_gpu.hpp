@@ -6,7 +6,9 @@
 //
 //   params::     parameter sets                     (params/params.go:83-112,117-146,151-180,362-391)
 //   tlwe::       TLWELv0 sample + linear ops        (tlwe/tlwe.go:11-33,76-134)
-//   trlwe::      TRLWELv1 sample                    (trlwe/trlwe.go:13-25)
+//   trlwe::      TRLWELv1 sample, SampleExtractIndex[Assign]   (trlwe/trlwe.go:13-25,114-131, trlwe_ops.go:10)
+//   trgsw::      TRGSWLv1FFT operand, ExternalProductWithFFT, CMUX, [Batch]BlindRotate,
+//                IdentityKeySwitching[Assign]        (trgsw/trgsw.go:108-252,285, keyswitch.go:10)
 //   cloudkey::   CloudKey resident on one GPU       (cloudkey/cloudkey.go:16-31)
 //   lut::        LookUpTable, Encoder, Generator    (lut/lut.go:13-45, encoder.go:10-107, generator.go:10-173)
 //   evaluator::  Evaluator {ExternalProductAssign, BlindRotateAssign, BootstrapAssign, Bootstrap,
