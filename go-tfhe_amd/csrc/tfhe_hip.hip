@@ -839,6 +839,20 @@ int gate_batch_pipelined(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const 
 // slots, so the upload of caller B runs on the transfer stream while caller A's kernels run, and A's results go down while B computes.
 // A lone caller goes through the same three phases back to back (two event waits more than the serial path).  The kernels themselves
 // still run one call at a time under the context mutex (they share the scratch), so results are exactly the serial path's.
+// An overlapped call that leaves on an error must not release its slot (or hand the caller's buffers back) while a copy or kernel of
+// it is still in flight: drained here on every exit that did not reach the end.
+struct SlotDrain {
+    tfhe_ctx *c;
+    bool armed = true;
+    ~SlotDrain()
+    {
+        if (!armed) return;
+        if (c->h2d_stream) (void)hipStreamSynchronize(c->h2d_stream);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->d2h_stream) (void)hipStreamSynchronize(c->d2h_stream);
+    }
+};
+
 // (called with up_mu held) the transfer streams and the slot's two events, made on first use
 int overlap_prepare(tfhe_ctx *c, tfhe_ctx::HostSlot &S)
 {
@@ -865,6 +879,7 @@ int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const
     HIP_TRY(hipSetDevice(c->device));
     tfhe_ctx::HostSlot &S = c->hslot[c->hticket.fetch_add(1, std::memory_order_relaxed) & 1];
     std::lock_guard<std::mutex> slot(S.mu);
+    SlotDrain drain{c};
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
     {
         std::lock_guard<std::mutex> up(c->up_mu);
@@ -882,10 +897,7 @@ int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         HIP_TRY(hipStreamWaitEvent(c->stream, S.up, 0));
         if ((rc = gate_batch_device(c, ops ? S.ops.as<uint8_t>() : nullptr, op_uniform, S.in0.as<uint32_t>(), S.in1.as<uint32_t>(),
-                                    cc ? S.in2.as<uint32_t>() : nullptr, S.out.as<uint32_t>(), B, c->stream))) {
-            (void)hipStreamSynchronize(c->stream);                    // nothing of this call may still read the slot when it is released
-            return rc;
-        }
+                                    cc ? S.in2.as<uint32_t>() : nullptr, S.out.as<uint32_t>(), B, c->stream))) return rc;
         HIP_TRY(hipEventRecord(S.done, c->stream));
     }
     {
@@ -894,6 +906,7 @@ int gate_batch_overlapped(tfhe_ctx *c, const uint8_t *ops, int op_uniform, const
         HIP_TRY(hipMemcpyAsync(out, S.out.p, rows, hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(hipStreamSynchronize(c->d2h_stream));
     }
+    drain.armed = false;
     return TFHE_OK;
 }
 
@@ -904,6 +917,7 @@ int bootstrap_batch_overlapped(tfhe_ctx *c, const uint32_t *in, const uint32_t *
     HIP_TRY(hipSetDevice(c->device));
     tfhe_ctx::HostSlot &S = c->hslot[c->hticket.fetch_add(1, std::memory_order_relaxed) & 1];
     std::lock_guard<std::mutex> slot(S.mu);
+    SlotDrain drain{c};
     const size_t rows = (size_t)B * (c->P.n + 1) * 4;
     const size_t tvb = tv ? (tv_per_item ? (size_t)B : 1) * 2 * c->P.N * 4 : 0;
     {
@@ -917,10 +931,7 @@ int bootstrap_batch_overlapped(tfhe_ctx *c, const uint32_t *in, const uint32_t *
     {
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         HIP_TRY(hipStreamWaitEvent(c->stream, S.up, 0));
-        if ((rc = bootstrap_device(c, S.in0.as<uint32_t>(), tv ? S.tv.as<uint32_t>() : nullptr, tv_per_item, S.out.as<uint32_t>(), B, c->stream))) {
-            (void)hipStreamSynchronize(c->stream);
-            return rc;
-        }
+        if ((rc = bootstrap_device(c, S.in0.as<uint32_t>(), tv ? S.tv.as<uint32_t>() : nullptr, tv_per_item, S.out.as<uint32_t>(), B, c->stream))) return rc;
         HIP_TRY(hipEventRecord(S.done, c->stream));
     }
     {
@@ -929,6 +940,7 @@ int bootstrap_batch_overlapped(tfhe_ctx *c, const uint32_t *in, const uint32_t *
         HIP_TRY(hipMemcpyAsync(out, S.out.p, rows, hipMemcpyDeviceToHost, c->d2h_stream));
         HIP_TRY(hipStreamSynchronize(c->d2h_stream));
     }
+    drain.armed = false;
     return TFHE_OK;
 }
 
