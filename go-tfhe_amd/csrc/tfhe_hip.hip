@@ -1211,7 +1211,7 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
         bt.filled.fetch_add(me.B, std::memory_order_release);
         while (bt.done.load(std::memory_order_acquire) == 0) futex_wait(bt.done, 0);
         const int rc = me.rc;
-        if (rc) g_err = me.err;
+        if (rc) { try { g_err = me.err; } catch (...) {} }
         else {
             const size_t n1b = ((size_t)c->P.n + 1) * 4;
             memcpy(me.out, comb_planes(c, Q, bt, me.kind).out + (size_t)me.pos * n1b, (size_t)me.B * n1b);
@@ -1328,7 +1328,7 @@ int combine_request(tfhe_ctx *c, tfhe_ctx::GateReq &me)
     bt.done.store(1, std::memory_order_release);
     futex_wake_all(bt.done);      // ONE system call for all sleepers (0.55 us each on the GPU box).  Measured and dropped (profiles/r06_c_combine.txt):
                                   // dealing the sleepers over four words with one relay waker per word -- every relay hop costs a thread wake-up, 134 vs 122 ms
-    if (rc) g_err = err;
+    if (rc) { try { g_err = err; } catch (...) {} }
     return rc;
 }
 
