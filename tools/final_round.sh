@@ -1,6 +1,7 @@
-cd $GRAFT_REPO_ROOT
-tools/collect_round.sh r06_t > gpurun_out/r06_t_collect.log 2>&1
-O=gpurun_out/r06_t
+# tools/final_round.sh [tag]: the round-end collection (collect_round.sh + sanitizers + 2-rank shared-GPU dry run + smoke)
+cd $GRAFT_REPO_ROOT; TAG=${1:-r06_t}
+tools/collect_round.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
+O=gpurun_out/$TAG
 for san in thread control address; do timeout 600 tools/asan_host_check.sh run $san > $O/san_$san.txt 2>&1; echo "rc=$?" >> $O/san_$san.txt; done
 # the N > 1 path of bench.py as a 2-rank dry run sharing the one GPU (gloo through host memory: RCCL refuses two ranks on one device)
 TFHE_BENCH_SHARE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 5 --warmup 2 --sustained-steps 100 --config5-gates 65536 > $O/weak_n2share.json 2> $O/weak_n2share.err; echo "n2share rc=$?" >> $O/weak_n2share.err
